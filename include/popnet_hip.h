@@ -1,0 +1,220 @@
+/*
+ * popnet_hip.h -- C ABI of libpopnet_hip.so, the MI355X (gfx950) implementation of the
+ * PoP-Net / MP-3DHP inference hot path:
+ *
+ *     depth frame -> resize/clamp/normalise -> CNN forward -> pose parsing -> 2D/3D joints
+ *
+ * Plain C types only (pointers, sizes, a HIP stream passed as void*): no torch, no C++ types.
+ * Device pointers are raw HIP allocations owned by the CALLER; the library owns only the
+ * workspace inside a pn_ctx / pn_net.  Every call returns 0 on success or a negative
+ * pn_status; the message is retrievable with pn_last_error().  Nothing aborts, nothing is
+ * global except the seven legacy `pafprocess` symbols at the end of this file.
+ *
+ * Each entry point cites the reference interface (file:line under /root/reference) it
+ * replaces.  "tpm/" = third_party_methods/.
+ */
+#ifndef POPNET_HIP_H
+#define POPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum pn_status {
+    PN_OK = 0,
+    PN_ERR_INVALID = -1,     /* bad argument / unknown tensor name / shape mismatch */
+    PN_ERR_HIP = -2,         /* a HIP runtime call failed (message has the hipError string) */
+    PN_ERR_STATE = -3,       /* call order violated (e.g. forward before finalize) */
+    PN_ERR_UNSUPPORTED = -4  /* shape outside what the kernels are built for */
+};
+
+/* ---- compute / storage precision of the conv stack ---------------------------------------- */
+enum pn_precision {
+    PN_PREC_F32 = 0,   /* fp32 storage, fp32-input MFMA (v_mfma_f32_16x16x4_f32): parity mode */
+    PN_PREC_BF16 = 1   /* bf16 storage, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate */
+};
+
+enum pn_net_kind {
+    PN_NET_RTPOSE_LIGHT3D = 0,  /* "Open-Pose+"  tpm/lib/network/rtpose_light3d.py:249-356 */
+    PN_NET_YOLO_POSENET = 1     /* "Yolo-Pose+"  tpm/lib/network/yolo_posenet.py:87-158   */
+};
+
+enum pn_depth_dtype { PN_DEPTH_F16 = 0, PN_DEPTH_F32 = 1 };
+
+typedef struct pn_ctx pn_ctx;
+typedef struct pn_net pn_net;
+
+/* ---- context -------------------------------------------------------------------------------
+ * One context per GPU / stream owner.  Not thread-safe per context; independent contexts are. */
+int pn_abi_version(void);
+pn_ctx *pn_create(int device_id);
+void pn_destroy(pn_ctx *ctx);
+/* Copies the last error message of this context into buf (NUL-terminated). Returns its length. */
+int pn_last_error(pn_ctx *ctx, char *buf, size_t buf_len);
+
+/* ---- pre-processing -------------------------------------------------------------------------
+ * Replaces test-mode KDH3D_Keypoints.__getitem__ image path:
+ *   tpm/lib/datasets/datasets_kdh3d_rtpose_mpreal.py:225-246 (CR line endings)
+ *   tpm/lib/datasets/data_augmentation_2d3d.py:76-89 (Cvt2ndarray), :507-522 (Resize, cv2 INTER_LINEAR)
+ * depth_dev: [B, H, W] f16 or f32 metres (device).  out_dev: [B, 1, S, S] f32 (device),
+ * = (clip(bilinear(depth), 0, depth_max) - depth_mean) / depth_std.                            */
+int pn_preprocess(pn_ctx *ctx, const void *depth_dev, int depth_dtype, int B, int H, int W,
+                  float *out_dev, int S, float depth_max, float depth_mean, float depth_std,
+                  void *hip_stream);
+
+/* ---- networks -------------------------------------------------------------------------------
+ * pn_net_create + pn_net_set_tensor + pn_net_finalize replace
+ *   model = rtpose_light3d(num_parts, num_limbs, num_stages, input_dim); model.load_state_dict(sd)
+ *   (tpm/evaluate/evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py:135-144)
+ * and the YoloPoseNet twin (tpm/evaluate/evaluation_yolo_posenet_kdh3d_mpreal.py:119-128).
+ * Tensor names are the reference state_dict keys, without "module.".
+ * `a` = num_limbs for rtpose_light3d, number of anchors for YoloPoseNet.                        */
+pn_net *pn_net_create(pn_ctx *ctx, int kind, int num_parts, int a, int input_dim);
+void pn_net_destroy(pn_net *net);
+/* Host fp32 data, copied.  Unknown names are rejected, except keys the reference builds but
+ * never executes (YoloPoseNet model0.layer3.*, *.num_batches_tracked), which are accepted and
+ * ignored. */
+int pn_net_set_tensor(pn_net *net, const char *name, const float *host_data,
+                      const int64_t *shape, int ndim);
+/* Folds BatchNorm (eval mode, eps 1e-5) into the convolutions, packs weights into MFMA
+ * fragment order, uploads, allocates NHWC activation workspace for `max_batch` frames of
+ * in_h x in_w.  Must be called once after all tensors are set. */
+int pn_net_finalize(pn_net *net, int precision, int max_batch, int in_h, int in_w);
+
+/* rtpose_light3d.forward (tpm/lib/network/rtpose_light3d.py:326-356), stage-2 outputs:
+ *   x_dev [B,1,in_h,in_w] f32 NCHW -> paf [B,2L,h,w], heat [B,J+1,h,w], z [B,L+1,h,w]
+ *   f32 NCHW device buffers (h = in_h/8).  Sigmoid range casts applied.                        */
+int pn_rtpose_forward(pn_net *net, const float *x_dev, int B, float *paf_dev, float *heat_dev,
+                      float *z_dev, void *hip_stream);
+/* YoloPoseNet.forward (tpm/lib/network/yolo_posenet.py:131-158):
+ *   x_dev [B,1,in_h,in_w] -> out [B, A*(5+3J), in_h/16, in_w/16] f32 NCHW, slice casts applied. */
+int pn_yolo_forward(pn_net *net, const float *x_dev, int B, float *out_dev, void *hip_stream);
+/* Test/diagnostic: copies a named internal activation of the last forward to the host as
+ * f32 NCHW.  Names: "feat" (stem output), "paf1" "heat1" "z1" (stage-1 outputs) for
+ * rtpose_light3d; "feat" (layer2 output) for YoloPoseNet.  Synchronises the stream.           */
+int pn_net_read_activation(pn_net *net, const char *name, int B, float *host_out,
+                           size_t host_elems, void *hip_stream);
+/* Same, device to device: writes f32 NCHW into dev_out on the stream, no synchronisation.  This is
+ * how the Python module materialises forward()'s `saved_for_loss` stage-1 entries
+ * (tpm/lib/network/rtpose_light3d.py:340-342).                                                   */
+int pn_net_copy_activation(pn_net *net, const char *name, int B, float *dev_out, void *hip_stream);
+/* Algorithmic FLOPs (2*MAC, convolutions only) of one frame through the finalized net. */
+double pn_net_flops_per_frame(pn_net *net);
+
+/* ---- Open-Pose+ parsing ---------------------------------------------------------------------
+ * Replaces, per frame, paf_to_pose + paf_to_human_list + the depth read-out / rescale /
+ * back-projection glue:
+ *   tpm/lib/utils/paf_to_pose.py:33-377, tpm/lib/utils/common.py:5-32,272-293,
+ *   tpm/evaluate/evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py:179-262.
+ * Limits are compile-time; exceeding one sets PN_FRAME_OVERFLOW in the frame's status and
+ * truncates deterministically (first-come in reference order).                                  */
+#define PN_NUM_JOINTS 15
+#define PN_NUM_LIMBS 14
+#define PN_MAX_PEAKS_PER_JOINT 32
+#define PN_MAX_PEAKS (PN_NUM_JOINTS * PN_MAX_PEAKS_PER_JOINT)
+#define PN_MAX_CONN_PER_LIMB PN_MAX_PEAKS_PER_JOINT
+#define PN_MAX_PERSONS 32
+
+#define PN_FRAME_OVERFLOW_PEAKS 1u
+#define PN_FRAME_OVERFLOW_PERSONS 2u
+
+typedef struct pn_parse_cfg {
+    float thresh_heatmap;      /* cfg.TEST.THRESH_HEATMAP  = 0.1   tpm/lib/config/default.py:126 */
+    float thresh_paf;          /* cfg.TEST.THRESH_PAF      = 0.05  :127 */
+    int   num_intermed_pts;    /* must be 10               :128 */
+    int   downsample;          /* must be 8  cfg.MODEL.DOWNSAMPLE :41 */
+    int   input_size;          /* 224: network input side, divisor of the rescale */
+    int   w_org, h_org;        /* original frame size for the rescale (480, 640) */
+    double fx, fy, cx, cy;     /* pinhole intrinsics  util/util_functions.py:4 */
+    float depth_mean, depth_std; /* 3, 2   util/util_functions.py:11-12 */
+} pn_parse_cfg;
+
+/* One frame of results.  Doubles where the reference keeps float64 (everything after NMS). */
+typedef struct pn_pose_frame {
+    int32_t  n_persons;
+    int32_t  n_peaks;                                   /* rows of joint_list */
+    uint32_t status;                                    /* PN_FRAME_OVERFLOW_* bits */
+    int32_t  reserved;
+    /* joint_list (paf_to_pose return value 0): x, y, score, id, type */
+    float    peak_x[PN_MAX_PEAKS];                      /* integer-valued pixel coords, 224 frame */
+    float    peak_y[PN_MAX_PEAKS];
+    float    peak_score[PN_MAX_PEAKS];
+    int32_t  peak_type[PN_MAX_PEAKS];
+    /* person_to_joint_assoc (return value 1): J joint ids (-1 = missing), score, count */
+    int32_t  person_joint[PN_MAX_PERSONS][PN_NUM_JOINTS];
+    double   person_score[PN_MAX_PERSONS];
+    int32_t  person_count[PN_MAX_PERSONS];
+    /* glue outputs, already rescaled to the original frame / back-projected */
+    double   joints_2d[PN_MAX_PERSONS][PN_NUM_JOINTS][2];   /* human_pred_set_2d entry   */
+    double   joints_3d[PN_MAX_PERSONS][PN_NUM_JOINTS][3];   /* human_pred_set_3d entry   */
+    double   part_conf[PN_MAX_PERSONS][PN_NUM_JOINTS];      /* human_pred_set_part_conf  */
+} pn_pose_frame;
+
+void pn_parse_cfg_default(pn_parse_cfg *cfg);
+/* heat [B,J+1,h,w], paf [B,2L,h,w], z [B,L+1,h,w]: f32 NCHW device buffers (z normalised, as
+ * the network emits it).  frames_dev: device array of B pn_pose_frame.                          */
+int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev,
+                 int B, int h, int w, const pn_parse_cfg *cfg, pn_pose_frame *frames_dev,
+                 void *hip_stream);
+
+/* retrieve_depth_heat_weighted(center, depthmap, heatmap, radius) (tpm/lib/utils/common.py:272-293)
+ * for n centres (x, y int32 pairs) on one [h, w] f32 map pair; like the reference it first clamps
+ * negative heat values in place.  out_dev: n float32 (the reference's np.sum/np.sum is float32).   */
+int pn_retrieve_depth(pn_ctx *ctx, const float *depthmap_dev, float *heatmap_dev, int h, int w,
+                      const int *centers_xy_dev, int n, int radius, float *out_dev, void *hip_stream);
+size_t pn_sizeof_pose_frame(void);
+
+/* ---- Yolo-Pose+ decode ----------------------------------------------------------------------
+ * Replaces parse_prior_pose (tpm/lib/utils/prior_pose_align.py:10-168, pred_vis=False), quirks
+ * included (candidate order anchor-major; suppression loop over rows 1..n-2; inclusive
+ * visibility test).  Unlike the reference it does NOT modify posemaps in place.               */
+#define PN_YOLO_MAX_DET 64
+typedef struct pn_yolo_frame {
+    int32_t n_det;                 /* surviving boxes (<= PN_YOLO_MAX_DET) */
+    int32_t n_candidates;          /* conf > threshold before NMS */
+    uint32_t status;               /* bit0: more than PN_YOLO_MAX_DET survivors (truncated) */
+    int32_t reserved;
+    float   bbox[PN_YOLO_MAX_DET][5];                 /* x1, y1, x2, y2, conf (pixels) */
+    float   human[PN_YOLO_MAX_DET][PN_NUM_JOINTS][3]; /* x, y (pixels), Z (metres) */
+    int32_t visibility[PN_YOLO_MAX_DET][PN_NUM_JOINTS];
+} pn_yolo_frame;
+
+int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w,
+                  const float *anchors_wh, int num_anchors, int num_joints, int w_out, int h_out,
+                  float depth_mean, float depth_std, float conf_threshold, float nms_threshold,
+                  int vis_margin, pn_yolo_frame *frames_dev, void *hip_stream);
+
+size_t pn_sizeof_yolo_frame(void);
+
+/* Host-only diagnostic: the four float32 bicubic taps (OpenCV interpolateCubic, A = -0.75) the
+ * parse kernels use for fractional offset x.  Lets CPU tests pin the table against the oracle.   */
+void pn_debug_cubic_coeffs(float x, float *out4);
+
+/* ---- legacy plug-in ABI: the SWIG module `pafprocess` -----------------------------------------
+ * Same seven symbols, same argument meaning and the same (non re-entrant, global-state)
+ * semantics as tpm/lib/pafprocess/pafprocess.h:53-59, COCO-18 topology (pafprocess.h:6-24).
+ * Inputs are HOST float32 C-contiguous arrays, borrowed for the duration of the call:
+ *   peaks [p1][p2][p3>=5] (x, y, score, -, part), heatmap [h1][h2][h3] (unused, as in the
+ *   reference), pafmap [f1][f2][f3=38].
+ * Differences: returns a negative pn_status instead of 0 when the GPU path fails; peaks that
+ * would index outside the PAF map are rejected instead of read out of bounds
+ * (pafprocess.cpp:232-233 has no bounds check).                                                 */
+int process_paf(int p1, int p2, int p3, float *peaks, int h1, int h2, int h3, float *heatmap,
+                int f1, int f2, int f3, float *pafmap);
+int get_num_humans(void);
+int get_part_cid(int human_id, int part_id);
+float get_score(int human_id);
+int get_part_x(int cid);
+int get_part_y(int cid);
+float get_part_score(int cid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPNET_HIP_H */

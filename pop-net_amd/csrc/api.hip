@@ -1,0 +1,134 @@
+// Context management + depth-frame pre-processing kernel.
+//
+// pn_preprocess replaces the image half of test-mode KDH3D_Keypoints.__getitem__:
+//   np.load(..).astype(float) -> float32                tpm/lib/datasets/datasets_kdh3d_rtpose_mpreal.py:225 (CR)
+//   cv2.resize(image, (S, S), INTER_LINEAR)             tpm/lib/datasets/data_augmentation_2d3d.py:507-510
+//   image[image < 0] = 0; image[image > depth_max] = .. tpm/lib/datasets/datasets_kdh3d_rtpose_mpreal.py:238-239 (CR)
+//   ToTensor + Normalize(depth_mean, depth_std)         ...:192-194,242 (CR)
+// The bilinear arithmetic follows OpenCV 4.2 resize.cpp's float path (see oracle/cv2_resize.py):
+// source coordinate computed in double and rounded to float, horizontal pass then vertical pass,
+// float32 products summed left to right, no fused multiply-add.  HBM-bound: reads 4 taps of the
+// f16 frame per output pixel (614 KB per 480x640 frame), writes S*S*4 B.
+#pragma clang fp contract(off)
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include "pn_internal.h"
+
+template <typename TIN>
+__global__ void preprocess_kernel(const TIN *__restrict__ depth, float *__restrict__ out, int B, int H, int W, int S,
+                                  double scale_x, double scale_y, float dmax, float mean, float stdv) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * S * S;
+    if (gid >= total) return;
+    int dx = (int)(gid % S);
+    size_t t = gid / S;
+    int dy = (int)(t % S);
+    int b = (int)(t / S);
+
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= W - 1) { sx = W - 1; fx = 0.f; }
+    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    int y0 = min(max(sy, 0), H - 1), y1 = min(max(sy + 1, 0), H - 1);
+
+    const TIN *img = depth + (size_t)b * H * W;
+    const float a0 = 1.f - fx, a1 = fx;
+    float h0, h1;
+    if (sx + 1 >= W) {      // HResizeLinear tail: D = S[sx] * 1
+        h0 = (float)img[(size_t)y0 * W + sx];
+        h1 = (float)img[(size_t)y1 * W + sx];
+    } else {
+        h0 = (float)img[(size_t)y0 * W + sx] * a0 + (float)img[(size_t)y0 * W + sx + 1] * a1;
+        h1 = (float)img[(size_t)y1 * W + sx] * a0 + (float)img[(size_t)y1 * W + sx + 1] * a1;
+    }
+    float v = h0 * (1.f - fy) + h1 * fy;
+    if (v < 0.f) v = 0.f;
+    if (v > dmax) v = dmax;
+    out[gid] = (v - mean) / stdv;
+}
+
+extern "C" {
+
+int pn_abi_version(void) { return PN_ABI_VERSION; }
+
+pn_ctx *pn_create(int device_id) {
+    pn_ctx *ctx = new pn_ctx();
+    ctx->device = device_id;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || device_id < 0 || device_id >= ndev) {
+        // keep the context so the caller can read the message; every later call fails cleanly
+        char buf[256];
+        snprintf(buf, sizeof buf, "pn_create: device %d not available (%d devices, %s)", device_id, ndev,
+                 hipGetErrorString(e));
+        ctx->err = buf;
+        ctx->device = -1;
+        return ctx;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    return ctx;
+}
+
+void pn_destroy(pn_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
+    delete ctx;
+}
+
+int pn_last_error(pn_ctx *ctx, char *buf, size_t buf_len) {
+    if (!ctx) return 0;
+    if (buf && buf_len) {
+        size_t n = ctx->err.size() < buf_len - 1 ? ctx->err.size() : buf_len - 1;
+        memcpy(buf, ctx->err.data(), n);
+        buf[n] = 0;
+    }
+    return (int)ctx->err.size();
+}
+
+int pn_preprocess(pn_ctx *ctx, const void *depth_dev, int depth_dtype, int B, int H, int W, float *out_dev, int S,
+                  float depth_max, float depth_mean, float depth_std, void *hip_stream) {
+    if (!ctx) return PN_ERR_INVALID;
+    if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
+    if (!depth_dev || !out_dev || B < 1 || H < 2 || W < 2 || S < 1)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_preprocess: bad arguments");
+    const double inv_x = (double)S / (double)W, inv_y = (double)S / (double)H;
+    const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;   // as cv::resize computes them
+    size_t total = (size_t)B * S * S;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (depth_dtype == PN_DEPTH_F16)
+        hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, block, 0, s, (const _Float16 *)depth_dev, out_dev, B, H, W, S,
+                           scale_x, scale_y, depth_max, depth_mean, depth_std);
+    else if (depth_dtype == PN_DEPTH_F32)
+        hipLaunchKernelGGL(preprocess_kernel<float>, grid, block, 0, s, (const float *)depth_dev, out_dev, B, H, W, S,
+                           scale_x, scale_y, depth_max, depth_mean, depth_std);
+    else
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_preprocess: unknown depth dtype %d", depth_dtype);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+void pn_parse_cfg_default(pn_parse_cfg *cfg) {
+    if (!cfg) return;
+    cfg->thresh_heatmap = 0.1f;
+    cfg->thresh_paf = 0.05f;
+    cfg->num_intermed_pts = 10;
+    cfg->downsample = 8;
+    cfg->input_size = 224;
+    cfg->w_org = 480;
+    cfg->h_org = 640;
+    cfg->fx = 504.1189880371094;
+    cfg->fy = 504.042724609375;
+    cfg->cx = 231.7421875;
+    cfg->cy = 320.62640380859375;
+    cfg->depth_mean = 3.f;
+    cfg->depth_std = 2.f;
+}
+
+}  // extern "C"

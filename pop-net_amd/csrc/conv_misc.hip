@@ -1,0 +1,186 @@
+// Bandwidth-bound companions of the MFMA convolution: the 7x7 stride-2 single-channel stem,
+// pooling, and NHWC -> NCHW export.  All are HBM/L2-streaming kernels (no matrix cores: Cin = 1
+// gives the stem an arithmetic intensity of ~46 flop/B).
+//
+//   stem   nn.Conv2d(1, 64, 7, stride 2, pad 3, bias=False) + BN + ReLU
+//          tpm/lib/network/rtpose_light3d.py:145-147,203-205 ; tpm/lib/network/yolo_posenet.py:33-36,46-48
+//   pools  nn.AvgPool2d(3, 2, 1) (count_include_pad -> divisor 9)  rtpose_light3d.py:152,158
+//          nn.MaxPool2d(3, 2, 1)                                   yolo_posenet.py:37
+//          nn.MaxPool2d(2, 2)                                      yolo_posenet.py:118
+#include "pn_internal.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------------
+// Stem.  Block = 16x16 output pixels of one image; the 37x37 input patch and the 49x64 weight
+// table sit in LDS.  Each thread produces all 64 output channels of one pixel (weights are read
+// as wave-wide LDS broadcasts), then writes one contiguous 128-B / 256-B NHWC pixel.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem7x7_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, T *__restrict__ out,
+                                                       int H, int W, int Ho, int Wo, int out_cs) {
+    __shared__ float tile[37][40];
+    __shared__ __attribute__((aligned(16))) float wl[49 * 64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    for (int i = tid; i < 49 * 64; i += 256) wl[i] = w[i];
+    const float *xb = x + (size_t)b * H * W;
+    for (int i = tid; i < 37 * 37; i += 256) {
+        int r = i / 37, cc = i - r * 37;
+        int iy = iy0 + r, ix = ix0 + cc;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[(size_t)iy * W + ix];
+        tile[r][cc] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const float xv = tile[ty * 2 + ky][tx * 2 + kx];
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(&wl[(ky * 7 + kx) * 64]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                f32x4 w4 = wp[i];
+                acc[4 * i + 0] = fmaf(xv, w4[0], acc[4 * i + 0]);
+                acc[4 * i + 1] = fmaf(xv, w4[1], acc[4 * i + 1]);
+                acc[4 * i + 2] = fmaf(xv, w4[2], acc[4 * i + 2]);
+                acc[4 * i + 3] = fmaf(xv, w4[3], acc[4 * i + 3]);
+            }
+        }
+    }
+    if (oy < Ho && ox < Wo) {
+        T *op = out + ((size_t)(b * Ho + oy) * Wo + ox) * out_cs;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            float v = acc[i] + bias[i];
+            op[i] = (T)(v > 0.f ? v : 0.f);
+        }
+    }
+}
+
+int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const float *bias, void *out,
+                   int B, int H, int W, int Ho, int Wo, int out_cs, hipStream_t stream) {
+    dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B), block(256);
+    if (prec == PN_PREC_BF16)
+        hipLaunchKernelGGL(stem7x7_kernel<__bf16>, grid, block, 0, stream, x, w, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs);
+    else
+        hipLaunchKernelGGL(stem7x7_kernel<float>, grid, block, 0, stream, x, w, bias, (float *)out, H, W, Ho, Wo, out_cs);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pooling on NHWC.  One thread = one output pixel x 8 channels (16 B of bf16 / 32 B of f32).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ void pool_kernel(const T *__restrict__ in, T *__restrict__ out, int B, int H, int W, int Ho, int Wo,
+                            int C8, int in_cs, int out_cs, int out_coff) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * Ho * Wo * C8;
+    if (gid >= total) return;
+    int c8 = (int)(gid % C8);
+    size_t p = gid / C8;
+    int ox = (int)(p % Wo);
+    size_t t = p / Wo;
+    int oy = (int)(t % Ho);
+    int b = (int)(t / Ho);
+    constexpr int K = (MODE == 2) ? 2 : 3;
+    constexpr int PAD = (MODE == 2) ? 0 : 1;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (MODE == 0) ? 0.f : -INFINITY;
+    for (int ky = 0; ky < K; ++ky) {
+        int iy = oy * 2 - PAD + ky;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < K; ++kx) {
+            int ix = ox * 2 - PAD + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const T *ip = in + ((size_t)(b * H + iy) * W + ix) * in_cs + c8 * 8;
+            T v[8];
+            if (sizeof(T) == 2) {
+                *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(ip);
+            } else {
+                reinterpret_cast<uint4 *>(v)[0] = reinterpret_cast<const uint4 *>(ip)[0];
+                reinterpret_cast<uint4 *>(v)[1] = reinterpret_cast<const uint4 *>(ip)[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float f = (float)v[i];
+                if (MODE == 0) acc[i] += f;
+                else acc[i] = fmaxf(acc[i], f);
+            }
+        }
+    }
+    T o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (T)((MODE == 0) ? acc[i] / 9.0f : acc[i]);
+    T *op = out + p * out_cs + out_coff + c8 * 8;
+    if (sizeof(T) == 2) {
+        *reinterpret_cast<uint4 *>(op) = *reinterpret_cast<uint4 *>(o);
+    } else {
+        reinterpret_cast<uint4 *>(op)[0] = reinterpret_cast<uint4 *>(o)[0];
+        reinterpret_cast<uint4 *>(op)[1] = reinterpret_cast<uint4 *>(o)[1];
+    }
+}
+
+template <typename T>
+static void launch_pool_t(int mode, const void *in, void *out, int B, int H, int W, int Ho, int Wo, int C,
+                          int in_cs, int out_cs, int out_coff, hipStream_t stream) {
+    size_t total = (size_t)B * Ho * Wo * (C / 8);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL((pool_kernel<T, 0>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff);
+    else if (mode == 1)
+        hipLaunchKernelGGL((pool_kernel<T, 1>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff);
+    else
+        hipLaunchKernelGGL((pool_kernel<T, 2>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff);
+}
+
+int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, int B, int H, int W, int C,
+                   int in_cs, int out_cs, int out_coff, hipStream_t stream) {
+    if (C % 8 || in_cs % 8 || out_cs % 8 || out_coff % 8)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pool: channels must be multiples of 8");
+    int Ho = (mode == 2) ? H / 2 : (H + 2 - 3) / 2 + 1;
+    int Wo = (mode == 2) ? W / 2 : (W + 2 - 3) / 2 + 1;
+    if (prec == PN_PREC_BF16) launch_pool_t<__bf16>(mode, in, out, B, H, W, Ho, Wo, C, in_cs, out_cs, out_coff, stream);
+    else launch_pool_t<float>(mode, in, out, B, H, W, Ho, Wo, C, in_cs, out_cs, out_coff, stream);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NHWC channel slice -> NCHW f32 (stage-1 outputs / diagnostics; not on the timed path).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T *__restrict__ in, float *__restrict__ out, int B, int HW, int C,
+                                    int in_cs, int in_coff) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * C * HW;
+    if (gid >= total) return;
+    int p = (int)(gid % HW);
+    size_t t = gid / HW;
+    int ch = (int)(t % C);
+    int b = (int)(t / C);
+    out[gid] = (float)in[((size_t)b * HW + p) * in_cs + in_coff + ch];
+}
+
+int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, int B, int H, int W, int C,
+                           int in_cs, int in_coff, hipStream_t stream) {
+    size_t total = (size_t)B * C * H * W;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (prec == PN_PREC_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, grid, block, 0, stream, (const __bf16 *)in, out, B, H * W, C, in_cs, in_coff);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, stream, (const float *)in, out, B, H * W, C, in_cs, in_coff);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}

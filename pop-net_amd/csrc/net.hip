@@ -1,0 +1,619 @@
+// Network objects: reference state_dict in, NHWC activation plan + MFMA-packed folded weights out.
+//
+// Mirrors (structure only; kernels are in conv_mfma.hip / conv_misc.hip):
+//   rtpose_light3d.__init__/forward   tpm/lib/network/rtpose_light3d.py:249-356
+//   ResPreprocessNet                  tpm/lib/network/rtpose_light3d.py:124-219
+//   YoloPoseNet / ResNetBackBone      tpm/lib/network/yolo_posenet.py:26-56,87-158
+// BatchNorm (eval, eps 1e-5) is folded into the preceding convolution at finalize time:
+//   w' = w * g / sqrt(var + eps),  b' = (b - mean) * g / sqrt(var + eps) + beta.
+// The stage-2 input "torch.cat([paf, heat, z, feat], 1)" (rtpose_light3d.py:339) is never copied:
+// the stem and the three stage-1 heads write straight into one 192-channel NHWC buffer laid out
+// [feat 0..127 | paf 128..155 | heat 156..171 | z 172..186 | 0-pad], and the stage-2 weights'
+// input channels are permuted to that order when they are packed.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+#include "pn_internal.h"
+
+namespace {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    size_t numel() const { return data.size(); }
+};
+
+struct Buf {
+    void *p = nullptr;
+    int H = 0, W = 0, C = 0;   // C = channel stride
+};
+
+struct ConvSpec {
+    std::string w;            // "<prefix>" of "<prefix>.weight" (and ".bias" when present)
+    std::string bn;           // BN prefix or ""
+    int ks = 3, stride = 1;
+    int in_buf = -1, in_coff = 0, cin = 0;
+    std::vector<int> cin_map; // my input channel -> reference input channel (-1 = zero); empty = identity
+    int out_buf = -1, out_coff = 0;
+    int res_buf = -1, res_coff = 0;
+    int act = PN_ACT_NONE;
+    int nchw_slot = -1;       // index into pn_net::nchw_ptr or -1
+    int cout = 0;
+    // derived
+    int cfg = 0, pitch = 0, R = 0, cin_chunks = 0;
+    void *wpack = nullptr;
+    float *bias = nullptr;
+    double flops = 0;
+};
+
+struct Step {
+    enum Type { STEM, POOL, CONV } type;
+    // STEM
+    int out_buf = -1;
+    float *stem_w = nullptr, *stem_b = nullptr;
+    // POOL
+    int mode = 0, in_buf = -1, C = 0, out_coff = 0;
+    // CONV: indices into pn_net::convs, all sharing one kernel instantiation
+    std::vector<int> conv_ids;
+    ConvLaunch launch;
+    std::vector<ConvProblem> host_probs;
+    ConvProblem *dev_probs = nullptr;
+};
+
+uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+struct pn_net {
+    pn_ctx *ctx = nullptr;
+    int kind = 0, num_parts = 15, a = 14, input_dim = 1;
+    std::map<std::string, HostTensor> tensors;
+    bool finalized = false;
+    int prec = PN_PREC_F32, max_batch = 0, in_h = 0, in_w = 0;
+    std::vector<Buf> bufs;
+    std::vector<ConvSpec> convs;
+    std::vector<Step> steps;
+    std::vector<void *> dev_allocs;
+    float *nchw_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    int last_B = -1;
+    float *last_nchw[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::map<std::string, std::pair<int, std::pair<int, int>>> named;   // name -> (buf, (coff, C))
+    double flops_per_frame = 0;
+    int out_h = 0, out_w = 0;
+
+    size_t esize() const { return prec == PN_PREC_BF16 ? 2 : 4; }
+};
+
+int pn_set_error(pn_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+namespace {
+
+const HostTensor *find_t(pn_net *n, const std::string &name) {
+    auto it = n->tensors.find(name);
+    return it == n->tensors.end() ? nullptr : &it->second;
+}
+
+int dev_alloc(pn_net *n, void **p, size_t bytes, bool zero) {
+    PN_HIP_CHECK(n->ctx, hipMalloc(p, bytes));
+    n->dev_allocs.push_back(*p);
+    if (zero) PN_HIP_CHECK(n->ctx, hipMemset(*p, 0, bytes));
+    return PN_OK;
+}
+
+int new_buf(pn_net *n, int H, int W, int C) {
+    Buf b;
+    b.H = H; b.W = W; b.C = C;
+    n->bufs.push_back(b);
+    return (int)n->bufs.size() - 1;
+}
+
+int pick_pitch(int cols) {
+    const int classes[4] = {16, 32, 64, 120};
+    for (int c : classes)
+        if (cols <= c) return c;
+    return -1;
+}
+
+int pick_cfg(int cout) {
+    if (cout % 128 == 0) return PN_CFG_C128;
+    if (cout >= 64) return PN_CFG_C64;
+    if (cout <= 16) return PN_CFG_C16;
+    return PN_CFG_C32;
+}
+
+// Fold BN, permute/pad input channels, pack into MFMA A-fragment order (see conv_mfma.hip).
+int prepare_conv(pn_net *n, ConvSpec &cs) {
+    pn_ctx *ctx = n->ctx;
+    const HostTensor *w = find_t(n, cs.w + ".weight");
+    if (!w || w->shape.size() != 4)
+        return pn_set_error(ctx, PN_ERR_INVALID, "missing conv weight %s.weight", cs.w.c_str());
+    const int cout = (int)w->shape[0], cin_ref = (int)w->shape[1], ks = (int)w->shape[2];
+    if (ks != cs.ks || (int)w->shape[3] != ks)
+        return pn_set_error(ctx, PN_ERR_INVALID, "%s.weight: kernel %dx%d, expected %d", cs.w.c_str(), ks, (int)w->shape[3], cs.ks);
+    cs.cout = cout;
+    std::vector<int> map = cs.cin_map;
+    if (map.empty()) {
+        map.resize(cin_ref);
+        for (int i = 0; i < cin_ref; ++i) map[i] = i;
+    }
+    for (int m : map)
+        if (m >= cin_ref)
+            return pn_set_error(ctx, PN_ERR_INVALID, "%s: input-channel map exceeds Cin=%d", cs.w.c_str(), cin_ref);
+    const int cin_pad = ((int)map.size() + 63) / 64 * 64;
+    map.resize(cin_pad, -1);
+    cs.cin_chunks = cin_pad / 64;
+    cs.cin = cin_ref;
+
+    std::vector<double> scale(cout, 1.0), shift(cout, 0.0);
+    const HostTensor *bias = find_t(n, cs.w + ".bias");
+    if (bias && (int)bias->numel() != cout) return pn_set_error(ctx, PN_ERR_INVALID, "%s.bias: bad size", cs.w.c_str());
+    for (int o = 0; o < cout; ++o) shift[o] = bias ? bias->data[o] : 0.0;
+    if (!cs.bn.empty()) {
+        const HostTensor *g = find_t(n, cs.bn + ".weight"), *be = find_t(n, cs.bn + ".bias");
+        const HostTensor *mu = find_t(n, cs.bn + ".running_mean"), *var = find_t(n, cs.bn + ".running_var");
+        if (!g || !be || !mu || !var || (int)g->numel() != cout || (int)be->numel() != cout ||
+            (int)mu->numel() != cout || (int)var->numel() != cout)
+            return pn_set_error(ctx, PN_ERR_INVALID, "missing/ill-shaped BatchNorm tensors %s.*", cs.bn.c_str());
+        for (int o = 0; o < cout; ++o) {
+            double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+            scale[o] = s;
+            shift[o] = (shift[o] - (double)mu->data[o]) * s + (double)be->data[o];
+        }
+    }
+
+    cs.cfg = pick_cfg(cout);
+    const int BC = pn_cfg_couts(cs.cfg);
+    const int cout_pad = (cout + BC - 1) / BC * BC;
+    const int ctiles = cout_pad / 16;
+    const int KK = ks * ks;
+    const int ksteps = cs.cin_chunks * KK * 2;
+    const size_t fragb = n->prec == PN_PREC_BF16 ? 1024 : 2048;
+    const size_t bytes = (size_t)ctiles * ksteps * fragb + fragb;   // + one spare fragment (prefetch overrun)
+    std::vector<unsigned char> host(bytes, 0);
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(host.data());
+    float *h32 = reinterpret_cast<float *>(host.data());
+    for (int ct = 0; ct < ctiles; ++ct)
+        for (int chunk = 0; chunk < cs.cin_chunks; ++chunk)
+            for (int tap = 0; tap < KK; ++tap)
+                for (int sub = 0; sub < 2; ++sub) {
+                    const size_t kstep = (size_t)(chunk * KK + tap) * 2 + sub;
+                    const size_t frag = (size_t)ct * ksteps + kstep;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = ct * 16 + (lane & 15), q = lane >> 4;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = map[chunk * 64 + sub * 32 + 8 * q + j];
+                            float v = 0.f;
+                            if (co < cout && ci >= 0)
+                                v = (float)((double)w->data[((size_t)co * cin_ref + ci) * KK + tap] * scale[co]);
+                            if (n->prec == PN_PREC_BF16) h16[(frag * 64 + lane) * 8 + j] = f32_to_bf16(v);
+                            else h32[frag * 512 + (size_t)(j >> 2) * 256 + lane * 4 + (j & 3)] = v;
+                        }
+                    }
+                }
+    if (int rc = dev_alloc(n, &cs.wpack, bytes, false)) return rc;
+    PN_HIP_CHECK(ctx, hipMemcpy(cs.wpack, host.data(), bytes, hipMemcpyHostToDevice));
+    std::vector<float> hb(cout_pad, 0.f);
+    for (int o = 0; o < cout; ++o) hb[o] = (float)shift[o];
+    if (int rc = dev_alloc(n, (void **)&cs.bias, hb.size() * 4, false)) return rc;
+    PN_HIP_CHECK(ctx, hipMemcpy(cs.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+
+    // geometry
+    const Buf &ib = n->bufs[cs.in_buf];
+    const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
+    const int BP = cs.cfg == PN_CFG_C128 ? 112 : 128;
+    if (Wo > BP) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: output width %d exceeds the %d-pixel block tile", cs.w.c_str(), Wo, BP);
+    cs.R = std::min(Ho, BP / Wo);
+    cs.pitch = pick_pitch((Wo - 1) * cs.stride + ks);
+    if (cs.pitch < 0) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo width %d has no pitch class", cs.w.c_str(), (Wo - 1) * cs.stride + ks);
+    cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
+    if (cs.out_buf >= 0) {
+        const Buf &ob = n->bufs[cs.out_buf];
+        if (ob.H != Ho || ob.W != Wo) return pn_set_error(ctx, PN_ERR_INVALID, "%s: output buffer is %dx%d, conv gives %dx%d", cs.w.c_str(), ob.H, ob.W, Ho, Wo);
+    }
+    return PN_OK;
+}
+
+int add_conv(pn_net *n, const std::string &w, const std::string &bn, int ks, int stride, int in_buf, int in_coff,
+             int out_buf, int out_coff, int act, int res_buf = -1, int nchw_slot = -1,
+             std::vector<int> cin_map = std::vector<int>()) {
+    ConvSpec cs;
+    cs.w = w; cs.bn = bn; cs.ks = ks; cs.stride = stride;
+    cs.in_buf = in_buf; cs.in_coff = in_coff;
+    cs.out_buf = out_buf; cs.out_coff = out_coff;
+    cs.res_buf = res_buf; cs.act = act; cs.nchw_slot = nchw_slot;
+    cs.cin_map = std::move(cin_map);
+    n->convs.push_back(cs);
+    return (int)n->convs.size() - 1;
+}
+
+void add_conv_level(pn_net *n, const std::vector<int> &ids) {
+    // split a set of independent convs into launches that share one kernel instantiation
+    std::vector<bool> used(ids.size(), false);
+    for (size_t i = 0; i < ids.size(); ++i) {
+        if (used[i]) continue;
+        Step st;
+        st.type = Step::CONV;
+        const ConvSpec &a = n->convs[ids[i]];
+        for (size_t j = i; j < ids.size(); ++j) {
+            const ConvSpec &b = n->convs[ids[j]];
+            if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.cfg == a.cfg && b.R == a.R) {
+                st.conv_ids.push_back(ids[j]);
+                used[j] = true;
+            }
+        }
+        n->steps.push_back(st);
+    }
+}
+
+void add_pool(pn_net *n, int mode, int in_buf, int out_buf, int C, int out_coff) {
+    Step st;
+    st.type = Step::POOL;
+    st.mode = mode; st.in_buf = in_buf; st.out_buf = out_buf; st.C = C; st.out_coff = out_coff;
+    n->steps.push_back(st);
+}
+
+int add_stem(pn_net *n, int out_buf) {
+    pn_ctx *ctx = n->ctx;
+    const HostTensor *w = find_t(n, "model0.conv1.weight");
+    if (!w || w->shape.size() != 4 || w->shape[0] != 64 || w->shape[1] != 1 || w->shape[2] != 7)
+        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "model0.conv1.weight must be [64,1,7,7] (single-channel depth input)");
+    const HostTensor *g = find_t(n, "model0.bn1.weight"), *be = find_t(n, "model0.bn1.bias");
+    const HostTensor *mu = find_t(n, "model0.bn1.running_mean"), *var = find_t(n, "model0.bn1.running_var");
+    if (!g || !be || !mu || !var) return pn_set_error(ctx, PN_ERR_INVALID, "missing model0.bn1.*");
+    std::vector<float> hw(49 * 64), hb(64);
+    for (int o = 0; o < 64; ++o) {
+        double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+        for (int t = 0; t < 49; ++t) hw[t * 64 + o] = (float)((double)w->data[o * 49 + t] * s);
+        hb[o] = (float)((0.0 - (double)mu->data[o]) * s + (double)be->data[o]);
+    }
+    Step st;
+    st.type = Step::STEM;
+    st.out_buf = out_buf;
+    if (int rc = dev_alloc(n, (void **)&st.stem_w, hw.size() * 4, false)) return rc;
+    if (int rc = dev_alloc(n, (void **)&st.stem_b, hb.size() * 4, false)) return rc;
+    PN_HIP_CHECK(ctx, hipMemcpy(st.stem_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    PN_HIP_CHECK(ctx, hipMemcpy(st.stem_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    n->steps.push_back(st);
+    n->flops_per_frame += 2.0 * n->bufs[out_buf].H * n->bufs[out_buf].W * 64.0 * 49.0;
+    return PN_OK;
+}
+
+// ---- graph builders -------------------------------------------------------------------------
+int build_rtpose(pn_net *n) {
+    const int H = n->in_h, W = n->in_w;
+    if (H % 8 || W % 8) return pn_set_error(n->ctx, PN_ERR_UNSUPPORTED, "input size must be a multiple of 8");
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int J1 = n->num_parts + 1, L2 = 2 * n->a, LZ = n->a + 1;      // heat / paf / z channels
+    if (L2 % 4 || J1 % 4) return pn_set_error(n->ctx, PN_ERR_UNSUPPORTED, "channel slices must be 4-aligned");
+    const int cat_c = (128 + L2 + J1 + LZ + 63) / 64 * 64;
+    const int off_paf = 128, off_heat = 128 + L2, off_z = 128 + L2 + J1;
+    n->out_h = H8; n->out_w = W8;
+
+    int A1 = new_buf(n, H2, W2, 64), A2 = new_buf(n, H2, W2, 64), T1 = new_buf(n, H2, W2, 64);
+    int P1 = new_buf(n, H4, W4, 64), T2 = new_buf(n, H4, W4, 128), D2 = new_buf(n, H4, W4, 128);
+    int A3 = new_buf(n, H4, W4, 128), A4 = new_buf(n, H4, W4, 128);
+    int CAT = new_buf(n, H8, W8, cat_c);
+    int BLa = new_buf(n, H8, W8, 256), BLb = new_buf(n, H8, W8, 256), BLc = new_buf(n, H8, W8, 128);
+    int BSa = new_buf(n, H8, W8, 128), BSb = new_buf(n, H8, W8, 128);
+    int BDa = new_buf(n, H8, W8, 128), BDb = new_buf(n, H8, W8, 64), BDc = new_buf(n, H8, W8, 64);
+    n->named["feat"] = {CAT, {0, 128}};
+    n->named["paf1"] = {CAT, {off_paf, L2}};
+    n->named["heat1"] = {CAT, {off_heat, J1}};
+    n->named["z1"] = {CAT, {off_z, LZ}};
+
+    if (int rc = add_stem(n, A1)) return rc;
+    std::vector<std::vector<int>> levels;
+    auto level = [&](std::vector<int> ids) { levels.push_back(ids); return 0; };
+    // layer1: two BasicBlocks(64) @ H/2
+    level({add_conv(n, "model0.layer1.0.conv1", "model0.layer1.0.bn1", 3, 1, A1, 0, T1, 0, PN_ACT_RELU)});
+    level({add_conv(n, "model0.layer1.0.conv2", "model0.layer1.0.bn2", 3, 1, T1, 0, A2, 0, PN_ACT_RELU, A1)});
+    level({add_conv(n, "model0.layer1.1.conv1", "model0.layer1.1.bn1", 3, 1, A2, 0, T1, 0, PN_ACT_RELU)});
+    level({add_conv(n, "model0.layer1.1.conv2", "model0.layer1.1.bn2", 3, 1, T1, 0, A1, 0, PN_ACT_RELU, A2)});
+    levels.push_back({-1, 0, A1, P1, 64, 0});    // avgpool1 marker: {-1, mode, in, out, C, out_coff}
+    // layer2: BasicBlock(64->128) with 1x1 shortcut @ H/4
+    level({add_conv(n, "model0.layer2.0.conv1", "model0.layer2.0.bn1", 3, 1, P1, 0, T2, 0, PN_ACT_RELU),
+           add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", 1, 1, P1, 0, D2, 0, PN_ACT_NONE)});
+    level({add_conv(n, "model0.layer2.0.conv2", "model0.layer2.0.bn2", 3, 1, T2, 0, A3, 0, PN_ACT_RELU, D2)});
+    level({add_conv(n, "model0.conv2", "model0.bn2", 1, 1, A3, 0, A4, 0, PN_ACT_RELU)});
+    levels.push_back({-1, 0, A4, CAT, 128, 0});  // avgpool2 -> feat slice of the concat buffer
+
+    // stage-2 input-channel map: my [feat | paf | heat | z | pad] -> reference [paf, heat, z, feat]
+    std::vector<int> map2(cat_c, -1);
+    for (int i = 0; i < 128; ++i) map2[i] = L2 + J1 + LZ + i;
+    for (int i = 0; i < L2; ++i) map2[off_paf + i] = i;
+    for (int i = 0; i < J1; ++i) map2[off_heat + i] = L2 + i;
+    for (int i = 0; i < LZ; ++i) map2[off_z + i] = L2 + J1 + i;
+
+    for (int stage = 1; stage <= 2; ++stage) {
+        char p1[32], p2[32], p3[32];
+        snprintf(p1, sizeof p1, "model%d_1", stage);
+        snprintf(p2, sizeof p2, "model%d_2", stage);
+        snprintf(p3, sizeof p3, "model%d_3", stage);
+        auto nm = [](const char *p, int i) { return std::string(p) + "." + std::to_string(i); };
+        std::vector<int> m = stage == 2 ? map2 : std::vector<int>();
+        const bool last = stage == 2;
+        level({add_conv(n, nm(p1, 0), nm(p1, 1), 3, 1, CAT, 0, BLa, 0, PN_ACT_LEAKY, -1, -1, m),
+               add_conv(n, nm(p2, 0), nm(p2, 1), 3, 1, CAT, 0, BSa, 0, PN_ACT_LEAKY, -1, -1, m),
+               add_conv(n, nm(p3, 0), nm(p3, 1), 3, 1, CAT, 0, BDa, 0, PN_ACT_LEAKY, -1, -1, m)});
+        level({add_conv(n, nm(p1, 3), nm(p1, 4), 3, 1, BLa, 0, BLb, 0, PN_ACT_LEAKY),
+               add_conv(n, nm(p2, 3), nm(p2, 4), 3, 1, BSa, 0, BSb, 0, PN_ACT_LEAKY),
+               add_conv(n, nm(p3, 3), nm(p3, 4), 3, 1, BDa, 0, BDb, 0, PN_ACT_LEAKY)});
+        level({add_conv(n, nm(p1, 6), nm(p1, 7), 3, 1, BLb, 0, BLa, 0, PN_ACT_LEAKY),
+               add_conv(n, nm(p2, 6), nm(p2, 7), 3, 1, BSb, 0, BSa, 0, PN_ACT_LEAKY),
+               add_conv(n, nm(p3, 6), nm(p3, 7), 3, 1, BDb, 0, BDc, 0, PN_ACT_LEAKY)});
+        level({add_conv(n, nm(p1, 9), nm(p1, 10), 1, 1, BLa, 0, BLc, 0, PN_ACT_LEAKY),
+               add_conv(n, nm(p2, 9), nm(p2, 10), 3, 1, BSa, 0, BSb, 0, PN_ACT_LEAKY),
+               add_conv(n, nm(p3, 9), nm(p3, 10), 3, 1, BDc, 0, BDb, 0, PN_ACT_LEAKY)});
+        level({add_conv(n, nm(p1, 12), "", 1, 1, BLc, 0, last ? -1 : CAT, off_paf, PN_ACT_SIG_PM2, -1, last ? 0 : -1),
+               add_conv(n, nm(p2, 12), "", 3, 1, BSb, 0, last ? -1 : CAT, off_heat, PN_ACT_SIG, -1, last ? 1 : -1),
+               add_conv(n, nm(p3, 12), "", 3, 1, BDb, 0, last ? -1 : CAT, off_z, PN_ACT_SIG_PM2, -1, last ? 2 : -1)});
+    }
+
+    for (auto &cs : n->convs)
+        if (int rc = prepare_conv(n, cs)) return rc;
+    for (auto &cs : n->convs) n->flops_per_frame += cs.flops;
+    for (auto &lv : levels) {
+        if (lv[0] == -1) add_pool(n, lv[1], lv[2], lv[3], lv[4], lv[5]);
+        else add_conv_level(n, lv);
+    }
+    return PN_OK;
+}
+
+int build_yolo(pn_net *n) {
+    const int H = n->in_h, W = n->in_w;
+    if (H % 16 || W % 16) return pn_set_error(n->ctx, PN_ERR_UNSUPPORTED, "input size must be a multiple of 16");
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16;
+    n->out_h = H16; n->out_w = W16;
+    int A1 = new_buf(n, H2, W2, 64);
+    int X0 = new_buf(n, H4, W4, 64), X1 = new_buf(n, H4, W4, 64), XT = new_buf(n, H4, W4, 64);
+    int Y0 = new_buf(n, H8, W8, 128), Y1 = new_buf(n, H8, W8, 128), YT = new_buf(n, H8, W8, 128), YD = new_buf(n, H8, W8, 128);
+    int Na = new_buf(n, H8, W8, 256), Nb = new_buf(n, H8, W8, 256);
+    int Ha = new_buf(n, H16, W16, 256), Hb = new_buf(n, H16, W16, 256), Hc = new_buf(n, H16, W16, 128);
+
+    if (int rc = add_stem(n, A1)) return rc;
+    std::vector<std::vector<int>> levels;
+    auto level = [&](std::vector<int> ids) { levels.push_back(ids); };
+    levels.push_back({-1, 1, A1, X0, 64, 0});   // maxpool 3x3 s2
+    int cur = X0, other = X1;
+    for (int i = 0; i < 3; ++i) {
+        std::string p = "model0.layer1." + std::to_string(i);
+        level({add_conv(n, p + ".conv1", p + ".bn1", 3, 1, cur, 0, XT, 0, PN_ACT_RELU)});
+        level({add_conv(n, p + ".conv2", p + ".bn2", 3, 1, XT, 0, other, 0, PN_ACT_RELU, cur)});
+        std::swap(cur, other);
+    }
+    level({add_conv(n, "model0.layer2.0.conv1", "model0.layer2.0.bn1", 3, 2, cur, 0, YT, 0, PN_ACT_RELU),
+           add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", 1, 2, cur, 0, YD, 0, PN_ACT_NONE)});
+    level({add_conv(n, "model0.layer2.0.conv2", "model0.layer2.0.bn2", 3, 1, YT, 0, Y0, 0, PN_ACT_RELU, YD)});
+    int yc = Y0, yo = Y1;
+    for (int i = 1; i < 4; ++i) {
+        std::string p = "model0.layer2." + std::to_string(i);
+        level({add_conv(n, p + ".conv1", p + ".bn1", 3, 1, yc, 0, YT, 0, PN_ACT_RELU)});
+        level({add_conv(n, p + ".conv2", p + ".bn2", 3, 1, YT, 0, yo, 0, PN_ACT_RELU, yc)});
+        std::swap(yc, yo);
+    }
+    n->named["feat"] = {yc, {0, 128}};
+    level({add_conv(n, "model1.0", "model1.1", 3, 1, yc, 0, Na, 0, PN_ACT_LEAKY)});
+    level({add_conv(n, "model1.3", "model1.4", 3, 1, Na, 0, Nb, 0, PN_ACT_LEAKY)});
+    level({add_conv(n, "model1.6", "model1.7", 3, 1, Nb, 0, Na, 0, PN_ACT_LEAKY)});
+    level({add_conv(n, "model1.9", "model1.10", 3, 1, Na, 0, Nb, 0, PN_ACT_LEAKY)});
+    level({add_conv(n, "model1.12", "", 3, 1, Nb, 0, Na, 0, PN_ACT_NONE)});
+    level({add_conv(n, "model2_1.0", "model2_1.1", 3, 1, Na, 0, Nb, 0, PN_ACT_LEAKY)});
+    levels.push_back({-1, 2, Nb, Ha, 256, 0});  // maxpool 2x2
+    level({add_conv(n, "model2_2.0", "model2_2.1", 3, 1, Ha, 0, Hb, 0, PN_ACT_LEAKY)});
+    level({add_conv(n, "model2_3.0", "model2_3.1", 3, 1, Hb, 0, Hc, 0, PN_ACT_LEAKY)});
+    level({add_conv(n, "model2_4.0", "", 3, 1, Hc, 0, -1, 0, PN_ACT_YOLO, -1, 3)});
+
+    for (auto &cs : n->convs)
+        if (int rc = prepare_conv(n, cs)) return rc;
+    for (auto &cs : n->convs) n->flops_per_frame += cs.flops;
+    for (auto &lv : levels) {
+        if (lv[0] == -1) add_pool(n, lv[1], lv[2], lv[3], lv[4], lv[5]);
+        else add_conv_level(n, lv);
+    }
+    return PN_OK;
+}
+
+int refresh_problems(pn_net *n, int B, hipStream_t stream) {
+    for (auto &st : n->steps) {
+        if (st.type != Step::CONV) continue;
+        const ConvSpec &c0 = n->convs[st.conv_ids[0]];
+        const int BC = pn_cfg_couts(c0.cfg);
+        st.host_probs.clear();
+        int max_blocks = 0;
+        for (int id : st.conv_ids) {
+            const ConvSpec &cs = n->convs[id];
+            const Buf &ib = n->bufs[cs.in_buf];
+            ConvProblem P;
+            memset(&P, 0, sizeof P);
+            const size_t es = n->esize();
+            (void)es;
+            P.in = ib.p;
+            P.wpack = cs.wpack;
+            P.bias = cs.bias;
+            P.B = B; P.H = ib.H; P.W = ib.W;
+            P.Ho = (ib.H + 2 * (cs.ks / 2) - cs.ks) / cs.stride + 1;
+            P.Wo = (ib.W + 2 * (cs.ks / 2) - cs.ks) / cs.stride + 1;
+            P.cin_chunks = cs.cin_chunks;
+            P.in_cs = ib.C; P.in_coff = cs.in_coff;
+            P.cout = cs.cout;
+            if (cs.out_buf >= 0) { P.out = n->bufs[cs.out_buf].p; P.out_cs = n->bufs[cs.out_buf].C; P.out_coff = cs.out_coff; }
+            if (cs.res_buf >= 0) { P.res = n->bufs[cs.res_buf].p; P.res_cs = n->bufs[cs.res_buf].C; P.res_coff = cs.res_coff; }
+            if (cs.nchw_slot >= 0) P.out_nchw = n->nchw_ptr[cs.nchw_slot];
+            P.act = cs.act;
+            P.yolo_naf = 5 + 3 * n->num_parts;
+            P.R = cs.R;
+            P.tiles_per_img = (P.Ho + cs.R - 1) / cs.R;
+            P.cout_blocks = (cs.cout + BC - 1) / BC;
+            P.nblocks = B * P.tiles_per_img * P.cout_blocks;
+            P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
+            max_blocks = std::max(max_blocks, P.nblocks);
+            st.host_probs.push_back(P);
+        }
+        st.launch.prec = n->prec;
+        st.launch.ks = c0.ks; st.launch.stride = c0.stride; st.launch.pitch = c0.pitch; st.launch.cfg = c0.cfg;
+        st.launch.nprob = (int)st.host_probs.size();
+        st.launch.max_blocks = max_blocks;
+        st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R);
+        st.launch.probs_dev = st.dev_probs;
+        PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),
+                                            hipMemcpyHostToDevice, stream));
+    }
+    n->last_B = B;
+    for (int i = 0; i < 4; ++i) n->last_nchw[i] = n->nchw_ptr[i];
+    return PN_OK;
+}
+
+int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
+    pn_ctx *ctx = n->ctx;
+    if (!n->finalized) return pn_set_error(ctx, PN_ERR_STATE, "pn_net_finalize has not been called");
+    if (B < 1 || B > n->max_batch) return pn_set_error(ctx, PN_ERR_INVALID, "batch %d outside [1, %d]", B, n->max_batch);
+    bool dirty = B != n->last_B;
+    for (int i = 0; i < 4; ++i) dirty |= n->nchw_ptr[i] != n->last_nchw[i];
+    if (dirty)
+        if (int rc = refresh_problems(n, B, stream)) return rc;
+    for (auto &st : n->steps) {
+        int rc = PN_OK;
+        if (st.type == Step::STEM) {
+            const Buf &ob = n->bufs[st.out_buf];
+            rc = pn_launch_stem(ctx, n->prec, x, st.stem_w, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, stream);
+        } else if (st.type == Step::POOL) {
+            const Buf &ib = n->bufs[st.in_buf], &ob = n->bufs[st.out_buf];
+            rc = pn_launch_pool(ctx, n->prec, st.mode, ib.p, ob.p, B, ib.H, ib.W, st.C, ib.C, ob.C, st.out_coff, stream);
+        } else {
+            rc = pn_launch_conv(ctx, st.launch, stream);
+        }
+        if (rc) return rc;
+    }
+    return PN_OK;
+}
+
+}  // namespace
+
+// ---- C ABI ----------------------------------------------------------------------------------
+extern "C" {
+
+pn_net *pn_net_create(pn_ctx *ctx, int kind, int num_parts, int a, int input_dim) {
+    if (!ctx) return nullptr;
+    if (kind != PN_NET_RTPOSE_LIGHT3D && kind != PN_NET_YOLO_POSENET) {
+        pn_set_error(ctx, PN_ERR_INVALID, "unknown net kind %d", kind);
+        return nullptr;
+    }
+    if (input_dim != 1) {
+        pn_set_error(ctx, PN_ERR_UNSUPPORTED, "only single-channel depth input (input_dim=1) is built");
+        return nullptr;
+    }
+    pn_net *n = new pn_net();
+    n->ctx = ctx; n->kind = kind; n->num_parts = num_parts; n->a = a; n->input_dim = input_dim;
+    return n;
+}
+
+void pn_net_destroy(pn_net *n) {
+    if (!n) return;
+    for (void *p : n->dev_allocs) (void)hipFree(p);
+    delete n;
+}
+
+int pn_net_set_tensor(pn_net *n, const char *name, const float *host_data, const int64_t *shape, int ndim) {
+    if (!n || !name || (!host_data && ndim > 0)) return PN_ERR_INVALID;
+    if (n->finalized) return pn_set_error(n->ctx, PN_ERR_STATE, "net already finalized");
+    std::string s(name);
+    if (s.rfind("module.", 0) == 0) s = s.substr(7);
+    HostTensor t;
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); numel *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + numel);
+    n->tensors[s] = std::move(t);
+    return PN_OK;
+}
+
+int pn_net_finalize(pn_net *n, int precision, int max_batch, int in_h, int in_w) {
+    if (!n) return PN_ERR_INVALID;
+    pn_ctx *ctx = n->ctx;
+    if (n->finalized) return pn_set_error(ctx, PN_ERR_STATE, "net already finalized");
+    if (precision != PN_PREC_F32 && precision != PN_PREC_BF16) return pn_set_error(ctx, PN_ERR_INVALID, "bad precision %d", precision);
+    if (max_batch < 1) return pn_set_error(ctx, PN_ERR_INVALID, "max_batch must be >= 1");
+    PN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    n->prec = precision; n->max_batch = max_batch; n->in_h = in_h; n->in_w = in_w;
+    int rc = n->kind == PN_NET_RTPOSE_LIGHT3D ? build_rtpose(n) : build_yolo(n);
+    if (rc) return rc;
+    for (auto &b : n->bufs) {
+        size_t bytes = (size_t)max_batch * b.H * b.W * b.C * n->esize();
+        if (int r = dev_alloc(n, &b.p, bytes, true)) return r;   // zero: pad channels must read as 0
+    }
+    for (auto &st : n->steps)
+        if (st.type == Step::CONV)
+            if (int r = dev_alloc(n, (void **)&st.dev_probs, st.conv_ids.size() * sizeof(ConvProblem), true)) return r;
+    n->tensors.clear();
+    n->finalized = true;
+    return PN_OK;
+}
+
+int pn_rtpose_forward(pn_net *n, const float *x_dev, int B, float *paf_dev, float *heat_dev, float *z_dev, void *hip_stream) {
+    if (!n) return PN_ERR_INVALID;
+    if (n->kind != PN_NET_RTPOSE_LIGHT3D) return pn_set_error(n->ctx, PN_ERR_INVALID, "not an rtpose_light3d net");
+    if (!x_dev || !paf_dev || !heat_dev || !z_dev) return pn_set_error(n->ctx, PN_ERR_INVALID, "null device pointer");
+    n->nchw_ptr[0] = paf_dev; n->nchw_ptr[1] = heat_dev; n->nchw_ptr[2] = z_dev;
+    return run_forward(n, x_dev, B, (hipStream_t)hip_stream);
+}
+
+int pn_yolo_forward(pn_net *n, const float *x_dev, int B, float *out_dev, void *hip_stream) {
+    if (!n) return PN_ERR_INVALID;
+    if (n->kind != PN_NET_YOLO_POSENET) return pn_set_error(n->ctx, PN_ERR_INVALID, "not a YoloPoseNet net");
+    if (!x_dev || !out_dev) return pn_set_error(n->ctx, PN_ERR_INVALID, "null device pointer");
+    n->nchw_ptr[3] = out_dev;
+    return run_forward(n, x_dev, B, (hipStream_t)hip_stream);
+}
+
+int pn_net_copy_activation(pn_net *n, const char *name, int B, float *dev_out, void *hip_stream) {
+    if (!n || !name || !dev_out) return PN_ERR_INVALID;
+    pn_ctx *ctx = n->ctx;
+    if (!n->finalized) return pn_set_error(ctx, PN_ERR_STATE, "net not finalized");
+    auto it = n->named.find(name);
+    if (it == n->named.end()) return pn_set_error(ctx, PN_ERR_INVALID, "unknown activation '%s'", name);
+    const Buf &b = n->bufs[it->second.first];
+    return pn_launch_nhwc_to_nchw(ctx, n->prec, b.p, dev_out, B, b.H, b.W, it->second.second.second, b.C,
+                                  it->second.second.first, (hipStream_t)hip_stream);
+}
+
+int pn_net_read_activation(pn_net *n, const char *name, int B, float *host_out, size_t host_elems, void *hip_stream) {
+    if (!n || !name || !host_out) return PN_ERR_INVALID;
+    pn_ctx *ctx = n->ctx;
+    auto it = n->named.find(name);
+    if (it == n->named.end()) return pn_set_error(ctx, PN_ERR_INVALID, "unknown activation '%s'", name);
+    const Buf &b = n->bufs[it->second.first];
+    const size_t elems = (size_t)B * it->second.second.second * b.H * b.W;
+    if (host_elems < elems) return pn_set_error(ctx, PN_ERR_INVALID, "host buffer too small: %zu < %zu", host_elems, elems);
+    float *tmp = nullptr;
+    PN_HIP_CHECK(ctx, hipMalloc((void **)&tmp, elems * 4));
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc = pn_net_copy_activation(n, name, B, tmp, hip_stream);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(host_out, tmp, elems * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = pn_set_error(ctx, PN_ERR_HIP, "read_activation copy: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+double pn_net_flops_per_frame(pn_net *n) { return n ? n->flops_per_frame : 0.0; }
+
+}  // extern "C"

@@ -1,0 +1,571 @@
+// Open-Pose+ pose parsing on the GPU: heat-map NMS with bicubic sub-cell refinement, part-affinity
+// limb scoring, greedy one-to-one matching, person assembly, depth read-out and back-projection.
+//
+// Replaces the reference's per-frame NumPy/SciPy/cv2 post-processing (Python loops on the host):
+//   find_peaks / NMS              tpm/lib/utils/paf_to_pose.py:33-153
+//   find_connected_joints         tpm/lib/utils/paf_to_pose.py:156-264
+//   group_limbs_of_same_person    tpm/lib/utils/paf_to_pose.py:267-351
+//   paf_to_human_list             tpm/lib/utils/common.py:5-32
+//   retrieve_depth_heat_weighted  tpm/lib/utils/common.py:272-293
+//   read-out / rescale / pinhole  tpm/evaluate/evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py:179-262
+//
+// Three launches per batch, all HBM/L2-latency bound (185 KB of maps in, <30 KB of records out per
+// frame); none materialises the reference's 224x224x28 up-sampled PAF tensor (5.6 MB/frame): the
+// x8 bicubic value is evaluated at the ten sample points of each candidate limb only.
+//   k1  one workgroup per (frame, joint map): peak flags -> ordered ballot compaction -> one wave
+//       per peak up-samples its <=5x5 patch x8 (<=40x40) and wave-reduces the first arg-max.
+//   k2  one workgroup per (frame, limb): lanes = (candidate pair, sample point); stable rank sort;
+//       greedy matching.
+//   k3  one wave per frame: sequential person assembly with wave-parallel row search, pruning,
+//       heat-weighted depth read-out, rescale and back-projection into fixed-size records.
+//
+// Arithmetic contract (bit-exact against oracle/parse_paf.py): float32 for everything the
+// reference computes from float32 maps (bicubic taps in OpenCV's order: horizontal pass then
+// vertical pass, products summed left to right), float64 for what NumPy promotes to float64
+// (sample coordinates, dot products, means, person scores, rescale, back-projection), NumPy's
+// pairwise summation order for np.mean / np.sum, round-half-even for np.round, and no fused
+// multiply-add anywhere in this file.
+#pragma clang fp contract(off)
+#include <cmath>
+#include "pn_internal.h"
+
+#define J_ PN_NUM_JOINTS
+#define L_ PN_NUM_LIMBS
+#define MAXP PN_MAX_PEAKS_PER_JOINT
+#define MAXC PN_MAX_CONN_PER_LIMB
+#define MAX_MAP 4096      // largest h*w the parse kernels stage in LDS (64 KB static-LDS budget)
+
+// limb topology: util/util_functions.py:17-34 == tpm/lib/datasets/datasets_itop_rtpose.py:45-62
+__constant__ int c_limb_src[L_] = {8, 9, 11, 8, 10, 12, 8, 1, 2, 4, 1, 3, 5, 1};
+__constant__ int c_limb_dst[L_] = {9, 11, 13, 10, 12, 14, 1, 2, 4, 6, 3, 5, 7, 0};
+
+struct CubicTab { float c[8][4]; };   // phase p: fractional offset (2p+1)/16
+
+struct ParseWs {                       // per-frame scratch between the three kernels
+    int peak_count[J_];                // uncapped count (overflow detection)
+    float peak_x[J_][MAXP], peak_y[J_][MAXP], peak_s[J_][MAXP];
+    int conn_count[L_];
+    int conn_i[L_][MAXC], conn_j[L_][MAXC];
+    double conn_s[L_][MAXC];
+};
+
+// interpolateCubic(x, coeffs), A = -0.75, float32 -- same expression order as oracle/cv2_resize.py
+static void host_cubic_coeffs(float x, float *c) {
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+    c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    const float xm = 1.f - x;
+    c[2] = ((A + 2.f) * xm - (A + 3.f)) * xm * xm + 1.f;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+extern "C" void pn_debug_cubic_coeffs(float x, float *out4) { host_cubic_coeffs(x, out4); }
+
+// destination index d of an x8 up-sampling -> first tap (sx - 1) and coefficient phase
+__device__ __forceinline__ void up8_src(int d, int &s0, int &phase) {
+    int t = 2 * d - 7;             // (d + 0.5) / 8 - 0.5 = t / 16, t odd
+    s0 = (t >> 4) - 1;             // floor(t/16) - 1
+    phase = (t & 15) >> 1;
+}
+
+// value of cv2.resize(src, fx=8, fy=8, INTER_CUBIC)[uy, ux] for a [sh, sw] float32 image with row
+// stride `ld` (replicate border): horizontal pass on the four source rows, then vertical pass.
+__device__ __forceinline__ float bicubic8(const float *src, int ld, int sh, int sw, int uy, int ux, const CubicTab &tab) {
+    int sx0, px, sy0, py;
+    up8_src(ux, sx0, px);
+    up8_src(uy, sy0, py);
+    int cx[4], cy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cx[k] = min(max(sx0 + k, 0), sw - 1);
+        cy[k] = min(max(sy0 + k, 0), sh - 1);
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float *row = src + cy[r] * ld;
+        float h = row[cx[0]] * tab.c[px][0];
+        h = h + row[cx[1]] * tab.c[px][1];
+        h = h + row[cx[2]] * tab.c[px][2];
+        h = h + row[cx[3]] * tab.c[px][3];
+        float t = h * tab.c[py][r];
+        v = (r == 0) ? t : v + t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k1: peaks + refinement.  grid = (J, B), block = 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void peaks_refine_kernel(const float *__restrict__ heat, int h, int w, int heat_c,
+                                                            float thresh, CubicTab tab, ParseWs *__restrict__ ws) {
+    __shared__ float map[MAX_MAP];
+    __shared__ int s_wave_cnt[4];
+    __shared__ int s_px[MAXP], s_py[MAXP];
+    __shared__ int s_total;
+    const int joint = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw = h * w;
+    const float *src = heat + ((size_t)b * heat_c + joint) * hw;
+    for (int i = tid; i < hw; i += 256) map[i] = src[i];
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+
+    // peak <=> v == max over the 4-connected cross (scipy 'reflect': an out-of-image neighbour is
+    // the pixel itself) and v > thresh; row-major order preserved by ordered compaction.
+    for (int base = 0; base < hw; base += 256) {
+        int i = base + tid;
+        bool pk = false;
+        if (i < hw) {
+            int y = i / w, x = i - y * w;
+            float v = map[i];
+            float m = v;
+            if (y > 0) m = fmaxf(m, map[i - w]);
+            if (y < h - 1) m = fmaxf(m, map[i + w]);
+            if (x > 0) m = fmaxf(m, map[i - 1]);
+            if (x < w - 1) m = fmaxf(m, map[i + 1]);
+            pk = (m == v) && (v > thresh);
+        }
+        unsigned long long bal = __ballot(pk);
+        if (lane == 0) s_wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_total;
+        for (int k = 0; k < wave; ++k) before += s_wave_cnt[k];
+        int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (pk && pos < MAXP) {
+            s_px[pos] = i % w;
+            s_py[pos] = i / w;
+        }
+        __syncthreads();
+        if (tid == 0) s_total += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        __syncthreads();
+    }
+    const int total = s_total;
+    ParseWs &W = ws[b];
+    if (tid == 0) W.peak_count[joint] = total;
+    const int n = min(total, MAXP);
+
+    // one wave per peak: x8 bicubic of the clipped 5x5 patch, first arg-max in row-major order
+    for (int p = wave; p < n; p += 4) {
+        const int px = s_px[p], py = s_py[p];
+        const int x_min = max(0, px - 2), y_min = max(0, py - 2);
+        const int x_max = min(w - 1, px + 2), y_max = min(h - 1, py + 2);
+        const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;
+        const int uw = pw * 8, un = uw * ph * 8;
+        const float *patch = map + y_min * w + x_min;
+        float best = -INFINITY;
+        int best_i = 0x7fffffff;
+        for (int i = lane; i < un; i += 64) {
+            int uy = i / uw, ux = i - uy * uw;
+            float v = bicubic8(patch, w, ph, pw, uy, ux, tab);
+            if (v > best || best_i == 0x7fffffff) { best = v; best_i = i; }   // i ascending: first max kept
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            float ov = __shfl_xor(best, off);
+            int oi = __shfl_xor(best_i, off);
+            if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+        }
+        if (lane == 0) {
+            int my = best_i / uw, mx = best_i - my * uw;
+            W.peak_x[joint][p] = (float)(8 * x_min + mx);
+            W.peak_y[joint][p] = (float)(8 * y_min + my);
+            W.peak_s[joint][p] = best;
+        }
+    }
+}
+
+// round-half-even of i*step + start (np.round(np.linspace(...))) as int
+__device__ __forceinline__ int linspace_round(double start, double stop, double step, int i, int num) {
+    double v = (i == num - 1) ? stop : ((double)i * step + start);
+    return (int)rint(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k2: limb scoring + greedy matching.  grid = (L, B), block = 256.
+// ---------------------------------------------------------------------------------------------
+#define PAIRS_PER_PASS 25      // 25 pairs x 10 sample points = 250 lanes busy per pass
+__global__ __launch_bounds__(256) void limb_match_kernel(const float *__restrict__ paf, int h, int w, int paf_c,
+                                                          float thresh_paf, int up_h, CubicTab tab,
+                                                          ParseWs *__restrict__ ws) {
+    __shared__ float pmap[2][MAX_MAP];
+    __shared__ double s_pts[PAIRS_PER_PASS][10];
+    __shared__ double s_cand_s[MAXP * MAXP];
+    __shared__ unsigned char s_cand_i[MAXP * MAXP], s_cand_j[MAXP * MAXP];
+    __shared__ unsigned short s_order[MAXP * MAXP];
+    __shared__ int s_ncand;
+    const int limb = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    ParseWs &W = ws[b];
+    const int jsrc = c_limb_src[limb], jdst = c_limb_dst[limb];
+    const int ns = min(W.peak_count[jsrc], MAXP), nd = min(W.peak_count[jdst], MAXP);
+    if (ns == 0 || nd == 0) {
+        if (tid == 0) W.conn_count[limb] = 0;
+        return;
+    }
+    const int hw = h * w;
+    const float *px_map = paf + ((size_t)b * paf_c + 2 * limb) * hw;
+    for (int i = tid; i < hw; i += 256) {
+        pmap[0][i] = px_map[i];
+        pmap[1][i] = px_map[hw + i];
+    }
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+
+    const int npairs = ns * nd;
+    for (int pbase = 0; pbase < npairs; pbase += PAIRS_PER_PASS) {
+        const int lp = tid / 10, pt = tid - lp * 10;
+        const int pair = pbase + lp;
+        const bool active = lp < PAIRS_PER_PASS && pair < npairs;
+        double sx = 0, sy = 0, dxn = 0, dyn = 0, dist = 1;
+        if (active) {
+            const int i = pair / nd, j = pair - i * nd;
+            sx = (double)W.peak_x[jsrc][i]; sy = (double)W.peak_y[jsrc][i];
+            const double ex = (double)W.peak_x[jdst][j], ey = (double)W.peak_y[jdst][j];
+            const double ddx = ex - sx, ddy = ey - sy;
+            dist = sqrt(ddx * ddx + ddy * ddy) + 1e-8;
+            dxn = ddx / dist; dyn = ddy / dist;
+            // np.linspace(start, stop, 10): step = (stop - start) / 9; y_i = i * step + start; y_9 = stop
+            const double stepx = (ex - sx) / 9.0, stepy = (ey - sy) / 9.0;
+            const int qx = linspace_round(sx, ex, stepx, pt, 10);
+            const int qy = linspace_round(sy, ey, stepy, pt, 10);
+            const float vx = bicubic8(pmap[0], w, h, w, qy, qx, tab);
+            const float vy = bicubic8(pmap[1], w, h, w, qy, qx, tab);
+            s_pts[lp][pt] = (double)vx * dxn + (double)vy * dyn;
+        }
+        __syncthreads();
+        // lanes 0..24 of wave 0 finish one pair each; ordered compaction keeps src-major order
+        if (tid < 64) {
+            bool ok = false;
+            double score = 0;
+            const int pr = pbase + tid;
+            if (tid < PAIRS_PER_PASS && pr < npairs) {
+                const double *s = s_pts[tid];
+                // np.mean of 10 float64: pairwise sum order of numpy for 8 <= n < 128
+                double res = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+                res = res + s[8];
+                res = res + s[9];
+                const double mean = res / 10.0;
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) cnt += (s[k] > (double)thresh_paf) ? 1 : 0;
+                // recompute this pair's length (lane-local): penalty min(0.5*H/dist - 1, 0)
+                const int i = pr / nd, j = pr - i * nd;
+                const double ax = (double)W.peak_x[jsrc][i], ay = (double)W.peak_y[jsrc][i];
+                const double bx = (double)W.peak_x[jdst][j], by = (double)W.peak_y[jdst][j];
+                const double ddx = bx - ax, ddy = by - ay;
+                const double dd = sqrt(ddx * ddx + ddy * ddy) + 1e-8;
+                const double pen = fmin(0.5 * (double)up_h / dd - 1.0, 0.0);
+                score = mean + pen;
+                ok = (cnt > 8) && (score > 0.0);      // > 0.8 * num_intermed_pts
+            }
+            unsigned long long bal = __ballot(ok);
+            const int basec = s_ncand;
+            if (ok) {
+                const int pos = basec + __popcll(bal & ((1ull << tid) - 1ull));
+                s_cand_s[pos] = score;
+                s_cand_i[pos] = (unsigned char)(pr / nd);
+                s_cand_j[pos] = (unsigned char)(pr % nd);
+            }
+            if (tid == 0) s_ncand = basec + __popcll(bal);
+        }
+        __syncthreads();
+    }
+
+    // stable descending sort by score (Python sorted(..., reverse=True) keeps insertion order on ties)
+    const int nc = s_ncand;
+    for (int k = tid; k < nc; k += 256) {
+        const double sk = s_cand_s[k];
+        int rank = 0;
+        for (int m = 0; m < nc; ++m) {
+            const double sm = s_cand_s[m];
+            rank += (sm > sk || (sm == sk && m < k)) ? 1 : 0;
+        }
+        s_order[rank] = (unsigned short)k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long used_i = 0, used_j = 0;
+        const int maxc = min(ns, nd);
+        int n = 0;
+        for (int r = 0; r < nc && n < maxc; ++r) {
+            const int k = s_order[r];
+            const int i = s_cand_i[k], j = s_cand_j[k];
+            if (!((used_i >> i) & 1ull) && !((used_j >> j) & 1ull)) {
+                used_i |= 1ull << i;
+                used_j |= 1ull << j;
+                W.conn_i[limb][n] = i;
+                W.conn_j[limb][n] = j;
+                W.conn_s[limb][n] = s_cand_s[k];
+                ++n;
+            }
+        }
+        W.conn_count[limb] = n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k3: person assembly + read-out.  grid = B, block = 64 (one wave).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void group_readout_kernel(const float *__restrict__ heat, const float *__restrict__ z,
+                                                            int h, int w, int heat_c, int z_c, pn_parse_cfg cfg,
+                                                            const ParseWs *__restrict__ ws, pn_pose_frame *__restrict__ frames) {
+    __shared__ double rows[PN_MAX_PERSONS][J_ + 2];
+    __shared__ int s_base[J_ + 1];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const ParseWs &W = ws[b];
+    pn_pose_frame &F = frames[b];
+    unsigned status = 0;
+
+    if (lane == 0) {
+        int acc = 0;
+        for (int j = 0; j < J_; ++j) {
+            s_base[j] = acc;
+            if (W.peak_count[j] > MAXP) status |= PN_FRAME_OVERFLOW_PEAKS;
+            acc += min(W.peak_count[j], MAXP);
+        }
+        s_base[J_] = acc;
+    }
+    __syncthreads();
+    const int npeaks = s_base[J_];
+    // joint_list rows (id == row index)
+    for (int j = 0; j < J_; ++j) {
+        const int n = min(W.peak_count[j], MAXP);
+        for (int k = lane; k < n; k += 64) {
+            const int id = s_base[j] + k;
+            F.peak_x[id] = W.peak_x[j][k];
+            F.peak_y[id] = W.peak_y[j][k];
+            F.peak_score[id] = W.peak_s[j][k];
+            F.peak_type[id] = j;
+        }
+    }
+
+    // ---- group_limbs_of_same_person (paf_to_pose.py:280-335), wave-uniform control flow ----
+    int np = 0;
+    for (int limb = 0; limb < L_; ++limb) {
+        const int st = c_limb_src[limb], dt = c_limb_dst[limb];
+        const int nconn = W.conn_count[limb];
+        for (int cidx = 0; cidx < nconn; ++cidx) {
+            const int ci = W.conn_i[limb][cidx], cj = W.conn_j[limb][cidx];
+            const double src_id = (double)(s_base[st] + ci), dst_id = (double)(s_base[dt] + cj);
+            const double lscore = W.conn_s[limb][cidx];
+            const double s_src = (double)W.peak_s[st][ci], s_dst = (double)W.peak_s[dt][cj];
+            bool hit = false;
+            if (lane < np) hit = (rows[lane][st] == src_id) || (rows[lane][dt] == dst_id);
+            const unsigned long long bal = __ballot(hit);
+            const int nh = __popcll(bal);
+            if (nh == 1) {
+                const int p = __ffsll((long long)bal) - 1;
+                if (lane == 0 && rows[p][dt] != dst_id) {
+                    rows[p][dt] = dst_id;
+                    rows[p][J_ + 1] += 1.0;
+                    rows[p][J_] += s_dst + lscore;
+                }
+            } else if (nh == 2) {
+                const int p1 = __ffsll((long long)bal) - 1;
+                const int p2 = __ffsll((long long)(bal & (bal - 1))) - 1;
+                bool both = false;
+                if (lane < J_) both = (rows[p1][lane] >= 0.0) && (rows[p2][lane] >= 0.0);
+                const bool overlap = __ballot(both) != 0ull;
+                if (!overlap) {
+                    if (lane < J_) rows[p1][lane] += rows[p2][lane] + 1.0;
+                    if (lane == 0) {
+                        rows[p1][J_] += rows[p2][J_];
+                        rows[p1][J_ + 1] += rows[p2][J_ + 1];
+                        rows[p1][J_] += lscore;
+                    }
+                    __syncthreads();
+                    // person_to_joint_assoc.pop(p2): shift the later rows down by one
+                    double tmp[J_ + 2];
+                    const bool mv = lane >= p2 && lane < np - 1;
+                    if (mv)
+                        for (int k = 0; k < J_ + 2; ++k) tmp[k] = rows[lane + 1][k];
+                    __syncthreads();
+                    if (mv)
+                        for (int k = 0; k < J_ + 2; ++k) rows[lane][k] = tmp[k];
+                    --np;
+                } else if (lane == 0) {
+                    rows[p1][dt] = dst_id;
+                    rows[p1][J_ + 1] += 1.0;
+                    rows[p1][J_] += s_dst + lscore;
+                }
+            } else {
+                if (np < PN_MAX_PERSONS) {
+                    if (lane < J_) rows[np][lane] = (lane == st) ? src_id : ((lane == dt) ? dst_id : -1.0);
+                    if (lane == 0) {
+                        rows[np][J_ + 1] = 2.0;
+                        rows[np][J_] = (s_src + s_dst) + lscore;      // sum([a, b]) + c
+                    }
+                    ++np;
+                } else {
+                    status |= PN_FRAME_OVERFLOW_PERSONS;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- prune (paf_to_pose.py:338-346) + read-out ----
+    bool keep = false;
+    if (lane < np) {
+        const double cnt = rows[lane][J_ + 1], sc = rows[lane][J_];
+        keep = !(cnt < 3.0 || sc / cnt < 0.2);
+    }
+    const unsigned long long kbal = __ballot(keep);
+    const int nkeep = __popcll(kbal);
+    if (keep) {
+        const int o = __popcll(kbal & ((1ull << lane) - 1ull));
+        for (int j = 0; j < J_; ++j) F.person_joint[o][j] = (int)rows[lane][j];
+        F.person_score[o] = rows[lane][J_];
+        F.person_count[o] = (int)rows[lane][J_ + 1];
+    }
+    if (lane == 0) {
+        F.n_persons = nkeep;
+        F.n_peaks = npeaks;
+        F.status = __shfl(status, 0) | status;
+        F.reserved = 0;
+    }
+
+    const int hw = h * w;
+    const float *heat_b = heat + (size_t)b * heat_c * hw;
+    const float *z_b = z + (size_t)b * z_c * hw;
+    const double dsz = (double)cfg.downsample;
+    for (int t = lane; t < nkeep * J_; t += 64) {
+        const int o = t / J_, j = t - o * J_;
+        // o-th kept row -> source row index
+        unsigned long long m = kbal;
+        for (int k = 0; k < o; ++k) m &= m - 1;
+        const int r = __ffsll((long long)m) - 1;
+        const int id = (int)rows[r][j];
+        double x2 = -1.0, y2 = -1.0, depth = -1.0, conf = 0.0;
+        if (id >= 0) {
+            const int k = id - s_base[j];
+            const double x = (double)W.peak_x[j][k], y = (double)W.peak_y[j][k];
+            conf = (double)W.peak_s[j][k];
+            // retrieve_depth_heat_weighted([int(x/8), int(y/8)], z*std+mean, heat, radius=1)
+            const int cx0 = (int)(x / dsz), cy0 = (int)(y / dsz);
+            const int min_x = min(max(cx0 - 1, 0), w - 1), max_x = max(min(cx0 + 1, w - 1), 0);
+            const int min_y = min(max(cy0 - 1, 0), h - 1), max_y = max(min(cy0 + 1, h - 1), 0);
+            const float *hm = heat_b + (size_t)j * hw;
+            const float *zm = z_b + (size_t)j * hw;
+            float pw_[9], ww_[9];
+            int n = 0;
+            for (int yy = min_y; yy <= max_y; ++yy)
+                for (int xx = min_x; xx <= max_x; ++xx) {
+                    float hv = hm[yy * w + xx];
+                    if (hv < 0.f) hv = 0.f;
+                    const float wv = hv + 0.000000001f;
+                    float dv = zm[yy * w + xx] * cfg.depth_std;
+                    dv = dv + cfg.depth_mean;
+                    pw_[n] = dv * wv;
+                    ww_[n] = wv;
+                    ++n;
+                }
+            float sp, sw;
+            if (n < 8) {            // numpy pairwise_sum, n < 8: sequential from -0.0
+                sp = -0.0f; sw = -0.0f;
+                for (int k2 = 0; k2 < n; ++k2) { sp = sp + pw_[k2]; sw = sw + ww_[k2]; }
+            } else {
+                sp = ((pw_[0] + pw_[1]) + (pw_[2] + pw_[3])) + ((pw_[4] + pw_[5]) + (pw_[6] + pw_[7]));
+                sw = ((ww_[0] + ww_[1]) + (ww_[2] + ww_[3])) + ((ww_[4] + ww_[5]) + (ww_[6] + ww_[7]));
+                for (int k2 = 8; k2 < n; ++k2) { sp = sp + pw_[k2]; sw = sw + ww_[k2]; }
+            }
+            depth = (double)(sp / sw);
+            x2 = x / (double)cfg.input_size * (double)cfg.w_org;
+            y2 = y / (double)cfg.input_size * (double)cfg.h_org;
+        }
+        F.joints_2d[o][j][0] = x2;
+        F.joints_2d[o][j][1] = y2;
+        F.joints_3d[o][j][0] = (x2 - cfg.cx) * depth / cfg.fx;
+        F.joints_3d[o][j][1] = (y2 - cfg.cy) * depth / cfg.fy;
+        F.joints_3d[o][j][2] = depth;
+        F.part_conf[o][j] = conf;
+    }
+}
+
+extern "C" int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev, int B, int h,
+                            int w, const pn_parse_cfg *cfg, pn_pose_frame *frames_dev, void *hip_stream) {
+    if (!ctx) return PN_ERR_INVALID;
+    if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
+    if (!heat_dev || !paf_dev || !z_dev || !cfg || !frames_dev || B < 1)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_parse_paf: bad arguments");
+    if (h * w > MAX_MAP || h < 1 || w < 1)
+        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_paf: map %dx%d exceeds %d cells", h, w, MAX_MAP);
+    if (cfg->downsample != 8 || cfg->num_intermed_pts != 10)
+        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_paf: built for downsample=8, 10 intermediate points");
+    const size_t need = (size_t)B * sizeof(ParseWs);
+    if (ctx->parse_ws_bytes < need) {
+        if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
+        ctx->parse_ws = nullptr;
+        ctx->parse_ws_bytes = 0;
+        PN_HIP_CHECK(ctx, hipMalloc(&ctx->parse_ws, need));
+        ctx->parse_ws_bytes = need;
+    }
+    CubicTab tab;
+    for (int p = 0; p < 8; ++p) host_cubic_coeffs((float)(2 * p + 1) / 16.0f, tab.c[p]);
+    hipStream_t s = (hipStream_t)hip_stream;
+    ParseWs *ws = (ParseWs *)ctx->parse_ws;
+    hipLaunchKernelGGL(peaks_refine_kernel, dim3(J_, B), dim3(256), 0, s, heat_dev, h, w, J_ + 1, cfg->thresh_heatmap, tab, ws);
+    hipLaunchKernelGGL(limb_match_kernel, dim3(L_, B), dim3(256), 0, s, paf_dev, h, w, 2 * L_, cfg->thresh_paf,
+                       h * cfg->downsample, tab, ws);
+    hipLaunchKernelGGL(group_readout_kernel, dim3(B), dim3(64), 0, s, heat_dev, z_dev, h, w, J_ + 1, L_ + 1, *cfg,
+                       (const ParseWs *)ws, frames_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone retrieve_depth_heat_weighted (tpm/lib/utils/common.py:272-293) for the per-call
+// Python API: n centres on one (depthmap, heatmap) pair, one lane per centre.  Like the reference
+// it clamps negative heat values IN PLACE in the caller's heat map before reading.
+// ---------------------------------------------------------------------------------------------
+__global__ void clamp_negative_kernel(float *__restrict__ hm, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && hm[i] < 0.f) hm[i] = 0.f;
+}
+
+__global__ void retrieve_depth_kernel(const float *__restrict__ dm, const float *__restrict__ hm, int h, int w,
+                                      const int *__restrict__ centers, int n, int radius, float *__restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int cx0 = centers[2 * t], cy0 = centers[2 * t + 1];
+    const int min_x = min(max(cx0 - radius, 0), w - 1), max_x = max(min(cx0 + radius, w - 1), 0);
+    const int min_y = min(max(cy0 - radius, 0), h - 1), max_y = max(min(cy0 + radius, h - 1), 0);
+    // np.sum over the [ny, nx] window: numpy pairwise summation (blocks of 8, then the tail)
+    const int nx = max_x - min_x + 1, cnt = nx * (max_y - min_y + 1);
+    float sp, sw;
+    auto P = [&](int k) { int yy = min_y + k / nx, xx = min_x + k % nx; return dm[yy * w + xx] * (hm[yy * w + xx] + 0.000000001f); };
+    auto Wt = [&](int k) { int yy = min_y + k / nx, xx = min_x + k % nx; return hm[yy * w + xx] + 0.000000001f; };
+    if (cnt < 8) {
+        sp = -0.0f; sw = -0.0f;
+        for (int k = 0; k < cnt; ++k) { sp = sp + P(k); sw = sw + Wt(k); }
+    } else if (cnt < 128) {
+        float rp[8], rw[8];
+        for (int k = 0; k < 8; ++k) { rp[k] = P(k); rw[k] = Wt(k); }
+        int i = 8;
+        for (; i < cnt - (cnt % 8); i += 8)
+            for (int k = 0; k < 8; ++k) { rp[k] = rp[k] + P(i + k); rw[k] = rw[k] + Wt(i + k); }
+        sp = ((rp[0] + rp[1]) + (rp[2] + rp[3])) + ((rp[4] + rp[5]) + (rp[6] + rp[7]));
+        sw = ((rw[0] + rw[1]) + (rw[2] + rw[3])) + ((rw[4] + rw[5]) + (rw[6] + rw[7]));
+        for (; i < cnt; ++i) { sp = sp + P(i); sw = sw + Wt(i); }
+    } else {
+        out[t] = __builtin_nanf("");      // windows of >= 128 cells are refused by the host wrapper
+        return;
+    }
+    out[t] = sp / sw;
+}
+
+extern "C" int pn_retrieve_depth(pn_ctx *ctx, const float *depthmap_dev, float *heatmap_dev, int h, int w,
+                                 const int *centers_xy_dev, int n, int radius, float *out_dev, void *hip_stream) {
+    if (!ctx) return PN_ERR_INVALID;
+    if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
+    if (!depthmap_dev || !heatmap_dev || !centers_xy_dev || !out_dev || n < 1 || radius < 0)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_retrieve_depth: bad arguments");
+    if ((2 * radius + 1) * (2 * radius + 1) >= 128)
+        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_retrieve_depth: radius %d too large", radius);
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(clamp_negative_kernel, dim3((h * w + 255) / 256), dim3(256), 0, s, heatmap_dev, h * w);
+    hipLaunchKernelGGL(retrieve_depth_kernel, dim3((n + 63) / 64), dim3(64), 0, s, depthmap_dev, (const float *)heatmap_dev,
+                       h, w, centers_xy_dev, n, radius, out_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}

@@ -1,0 +1,99 @@
+// Internal declarations shared by the HIP translation units of libpopnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/popnet_hip.h"
+
+struct pn_ctx {
+    int device = 0;
+    std::string err;
+    int num_cus = 256;
+    // scratch for the parse kernels (grown on demand, owned by the ctx)
+    void *parse_ws = nullptr;
+    size_t parse_ws_bytes = 0;
+};
+
+int pn_set_error(pn_ctx *ctx, int code, const char *fmt, ...);
+
+#define PN_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return pn_set_error((ctx), PN_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                                hipGetErrorString(_e), __FILE__, __LINE__);                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Convolution problem descriptor (device-visible).  One launch handles a GROUP of problems that
+// share a kernel instantiation (blockIdx.y = problem), e.g. the three branches of a stage.
+// Activations are NHWC with a channel stride (so a tensor can be a channel slice of a wider
+// buffer: the stage-2 "concat" is never materialised by a copy).
+// ---------------------------------------------------------------------------------------------
+enum pn_act {
+    PN_ACT_NONE = 0,
+    PN_ACT_RELU = 1,
+    PN_ACT_LEAKY = 2,        // LeakyReLU(0.1)
+    PN_ACT_SIG_PM2 = 3,      // (sigmoid(x) - 0.5) * 4   rtpose_light3d.py:335,337
+    PN_ACT_SIG = 4,          // sigmoid(x)               rtpose_light3d.py:336
+    PN_ACT_YOLO = 5          // per-slice casts          yolo_posenet.py:146-156
+};
+
+struct ConvProblem {
+    const void *in;        // NHWC activations (element type T)
+    const void *wpack;     // weights in MFMA fragment order (see pack_conv_weights)
+    const float *bias;     // folded bias, padded to cout tiles
+    const void *res;       // residual NHWC (T) or nullptr; added before the activation
+    void *out;             // NHWC (T) output or nullptr
+    float *out_nchw;       // NCHW f32 output or nullptr
+    int B, H, W;           // input spatial size
+    int Ho, Wo;            // output spatial size
+    int cin_chunks;        // padded Cin / 64
+    int in_cs, in_coff;    // input channel stride / first channel
+    int cout;              // valid output channels
+    int out_cs, out_coff;
+    int res_cs, res_coff;
+    int act;
+    int yolo_naf;          // channels per anchor for PN_ACT_YOLO (5 + 3J)
+    int R;                 // output rows per block
+    int tiles_per_img;     // ceil(Ho / R)
+    int cout_blocks;       // ceil(cout / (WC*CT*16))
+    int nblocks;           // B * tiles_per_img * cout_blocks
+    int ksteps;            // cin_chunks * KS*KS * 2   (k32 steps per cout tile in wpack)
+};
+
+// Tile configuration ids (see conv_mfma.hip).
+enum pn_conv_cfg {
+    PN_CFG_C128 = 0,  // 4x1 waves, 2 cout tiles x 7 pixel tiles per wave: 128 couts x 112 px
+    PN_CFG_C64 = 1,   // 2x2 waves, 2 cout tiles x 4 pixel tiles per wave:  64 couts x 128 px
+    PN_CFG_C32 = 2,   // 1x4 waves, 2 cout tiles x 2 pixel tiles per wave:  32 couts x 128 px
+    PN_CFG_C16 = 3    // 1x4 waves, 1 cout tile  x 2 pixel tiles per wave:  16 couts x 128 px
+};
+int pn_cfg_couts(int cfg);
+
+struct ConvLaunch {
+    int prec;      // pn_precision
+    int ks;        // 1 or 3
+    int stride;    // 1 or 2
+    int pitch;     // LDS halo row pitch in pixels (multiple of 8, >= halo columns)
+    int cfg;       // pn_conv_cfg
+    int nprob;
+    int max_blocks;          // max nblocks over the group
+    size_t lds_bytes;
+    const ConvProblem *probs_dev;
+};
+int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
+size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
+
+// stem: 7x7 stride-2 pad-3, Cin = 1, fused folded-BN bias + ReLU.  x NCHW f32 [B,1,H,W] ->
+// NHWC T [B,Ho,Wo,64].  w [49][64] f32 (tap-major), bias [64].
+int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const float *bias,
+                   void *out, int B, int H, int W, int Ho, int Wo, int out_cs, hipStream_t stream);
+
+// pooling on NHWC T.  mode 0: avg 3x3 s2 p1 (count_include_pad), 1: max 3x3 s2 p1, 2: max 2x2 s2.
+int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, int B, int H, int W,
+                   int C, int in_cs, int out_cs, int out_coff, hipStream_t stream);
+
+// NHWC T channel slice -> NCHW f32 (diagnostics / stage-1 outputs).
+int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, int B, int H, int W,
+                           int C, int in_cs, int in_coff, hipStream_t stream);

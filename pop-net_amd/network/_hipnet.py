@@ -1,0 +1,123 @@
+"""Shared machinery of the two network modules: turns an ``nn.Module`` that merely HOLDS the
+reference-format parameters into a compiled ``pn_net`` (BN folded, weights packed for MFMA) and
+runs forward through the C ABI.  No PyTorch convolution is ever called."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+_PREC = {"fp32": _lib.PN_PREC_F32, "f32": _lib.PN_PREC_F32, "bf16": _lib.PN_PREC_BF16}
+
+
+def default_precision():
+    return os.environ.get("POPNET_PRECISION", "fp32")
+
+
+class HipNetModule(nn.Module):
+    """Base class.  Subclasses define the parameter-holding sub-modules (same names as the
+    reference, so ``state_dict()`` / ``load_state_dict()`` are interchangeable) and ``_kind``.
+
+    precision: "fp32" (parity mode: fp32 storage + fp32-input MFMA) or "bf16" (bf16 storage,
+    bf16 MFMA, fp32 accumulate).  Default: $POPNET_PRECISION or "fp32".
+    """
+    _kind = None
+
+    def __init__(self):
+        super().__init__()
+        self.precision = default_precision()
+        self._net = None          # (handle, key)
+        self._ctx = None
+
+    # ---- compilation ----------------------------------------------------------------------
+    def _net_args(self):
+        raise NotImplementedError
+
+    def _weights_version(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _release(self):
+        if self._net is not None:
+            _lib.lib().pn_net_destroy(self._net[0])
+            self._net = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def invalidate(self):
+        """Forces re-folding / re-packing of the weights on the next forward."""
+        self._release()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # reference checkpoints come from a DataParallel wrapper ("module." prefix,
+        # tpm/evaluate/evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py:136-139)
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate()
+        return out
+
+    def _compile(self, device, batch, in_h, in_w):
+        if self.training:
+            raise _lib.PopnetError("popnet_amd: only eval-mode inference is built (call .eval()); "
+                                   "training-mode BatchNorm / backward are not part of this path")
+        prec = _PREC.get(str(self.precision).lower())
+        if prec is None:
+            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
+        key = (device.index, prec, in_h, in_w, self._weights_version())
+        if self._net is not None and self._net[1] == key and self._net[2] >= batch:
+            return self._net[0]
+        self._release()
+        L = _lib.lib()
+        ctx = _lib.Context.for_device(device.index)
+        self._ctx = ctx
+        kind, num_parts, a, input_dim = self._net_args()
+        h = L.pn_net_create(ctx.handle, kind, num_parts, a, input_dim)
+        if not h:
+            raise _lib.PopnetError("pn_net_create failed: " + ctx.last_error())
+        try:
+            for name, t in self.state_dict().items():
+                if name.endswith("num_batches_tracked") or name.startswith("model0.layer3."):
+                    continue      # never executed by the reference forward (yolo_posenet.py:42,54)
+                arr = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+                shape = (C.c_int64 * arr.ndim)(*arr.shape)
+                ctx.check(L.pn_net_set_tensor(h, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim),
+                          "pn_net_set_tensor(%s)" % name)
+            max_batch = max(batch, int(os.environ.get("POPNET_MAX_BATCH", "0")))
+            ctx.check(L.pn_net_finalize(h, prec, max_batch, in_h, in_w), "pn_net_finalize")
+        except Exception:
+            L.pn_net_destroy(h)
+            raise
+        self._net = (h, key, max_batch)
+        return h
+
+    def flops_per_frame(self):
+        if self._net is None:
+            raise _lib.PopnetError("net not compiled yet (run a forward first)")
+        return _lib.lib().pn_net_flops_per_frame(self._net[0])
+
+    def _check_input(self, x):
+        _lib.require_cuda_tensor(x, "input")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise _lib.PopnetError("expected a [B,1,H,W] depth batch, got %s" % (tuple(x.shape),))
+        return x.contiguous().float()
+
+    def _activation(self, name, B, shape, device):
+        out = torch.empty((B,) + shape, device=device, dtype=torch.float32)
+        self._ctx.check(_lib.lib().pn_net_copy_activation(self._net[0], name.encode(), B, C.c_void_p(out.data_ptr()),
+                                                          _lib.current_stream_ptr(device)), "pn_net_copy_activation")
+        return out
+
+
+def bn_(c):
+    return nn.BatchNorm2d(c)
+
+
+def conv_(cin, cout, k, stride=1, bias=False):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=bias)

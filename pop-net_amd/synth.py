@@ -1,0 +1,146 @@
+"""Deterministic synthetic inputs shared by tests, golden-vector generation and bench.py.
+
+No dataset or trained weights ship with the reference, so everything is seeded:
+  * ``fill_state_dict``   weights keyed by parameter NAME (independent of module construction
+                          order, so the reference modules and ours get identical tensors);
+  * ``planted_maps``      network-output-like maps with P planted 15-joint skeletons
+                          (Gaussian heat blobs, unit-vector PAF ribbons, constant z per person);
+  * ``synth_depth``       depth frames shaped like MP-3DHP (480 wide x 640 high, metres, f16).
+"""
+import zlib
+
+import numpy as np
+
+from .config import LIMBS
+
+
+def _rng_for(name, seed):
+    return np.random.default_rng([zlib.crc32(name.encode()) & 0xffffffff, seed])
+
+
+def fill_state_dict(sd, seed=0, gain=1.0):
+    """Fills (a copy of) a torch state_dict in place-compatible form; returns {name: ndarray}.
+    Conv weights ~ N(0, gain*sqrt(2/fan_in)) so activations keep O(1) scale through the stack
+    (the reference's N(0, 0.01) init collapses every map to sigmoid(0)); BatchNorm affine and
+    running statistics are randomised so folding is actually exercised."""
+    out = {}
+    for name, t in sd.items():
+        shape = tuple(t.shape)
+        rng = _rng_for(name, seed)
+        if name.endswith("num_batches_tracked"):
+            out[name] = np.zeros(shape, dtype=np.int64)
+        elif name.endswith("running_mean"):
+            out[name] = rng.normal(0, 0.05, shape).astype(np.float32)
+        elif name.endswith("running_var"):
+            out[name] = rng.uniform(0.8, 1.2, shape).astype(np.float32)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            out[name] = (rng.standard_normal(shape) * gain * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif name.endswith(".weight"):            # BatchNorm gamma
+            out[name] = rng.uniform(0.8, 1.2, shape).astype(np.float32)
+        else:                                      # conv / BatchNorm bias
+            out[name] = rng.normal(0, 0.05, shape).astype(np.float32)
+    return out
+
+
+def load_synth_weights(model, seed=0, gain=1.0):
+    import torch
+    arrays = fill_state_dict(model.state_dict(), seed, gain)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in arrays.items()})
+    return model
+
+
+# a standing person in a unit box: (x, y) of the 15 joints, y down
+_TEMPLATE = np.array([
+    [0.50, 0.05],  # head
+    [0.50, 0.18],  # neck
+    [0.36, 0.22], [0.64, 0.22],   # shoulders r, l
+    [0.30, 0.38], [0.70, 0.38],   # elbows
+    [0.27, 0.53], [0.73, 0.53],   # wrists
+    [0.50, 0.45],  # torso
+    [0.42, 0.55], [0.58, 0.55],   # hips
+    [0.40, 0.75], [0.60, 0.75],   # knees
+    [0.39, 0.95], [0.61, 0.95],   # ankles
+])
+
+
+def planted_persons(rng, n_persons, size=224, min_h=110, max_h=200):
+    """Joint positions [P,15,2] in input-pixel coordinates plus a depth per person."""
+    persons = []
+    for _ in range(n_persons):
+        hgt = rng.uniform(min_h, max_h)
+        wid = hgt * rng.uniform(0.45, 0.6)
+        x0 = rng.uniform(2, size - wid - 2)
+        y0 = rng.uniform(2, size - hgt - 2)
+        jit = rng.normal(0, 0.01, _TEMPLATE.shape)
+        pts = (_TEMPLATE + jit) * [wid, hgt] + [x0, y0]
+        persons.append(np.clip(pts, 1, size - 2))
+    return np.array(persons).reshape(n_persons, 15, 2), rng.uniform(1.5, 4.5, n_persons)
+
+
+def planted_maps(seed, n_persons, h=28, w=28, stride=8, sigma=0.8, noise=0.01, drop_prob=0.0):
+    """Returns (heat [h,w,16], paf [h,w,28], z [h,w,15]) float32 HWC, like the network emits them
+    (heat in (0,1), paf in (-2,2), z normalised), with n_persons planted skeletons."""
+    rng = np.random.default_rng([seed, n_persons, 7])
+    joints, depths = planted_persons(rng, n_persons, size=h * stride)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    heat = np.zeros((h, w, 16))
+    paf = np.zeros((h, w, 28))
+    cnt = np.zeros((h, w, 14))
+    z = np.zeros((h, w, 15))
+    for p in range(n_persons):
+        jc = joints[p] / stride - 0.5 + 0.5            # joint position in cell units (cell centre = +0.5)
+        present = rng.random(15) >= drop_prob
+        for j in range(15):
+            if not present[j]:
+                continue
+            g = np.exp(-((xx + 0.5 - jc[j, 0]) ** 2 + (yy + 0.5 - jc[j, 1]) ** 2) / (2 * sigma ** 2))
+            heat[:, :, j] = np.maximum(heat[:, :, j], 0.9 * g)
+            near = g > 0.05
+            z[:, :, j][near] = (depths[p] - 3.0) / 2.0
+        for l, (a, b) in enumerate(LIMBS):
+            if not (present[a] and present[b]):
+                continue
+            pa, pb = jc[a], jc[b]
+            d = pb - pa
+            n = np.hypot(*d)
+            if n < 1e-6:
+                continue
+            u = d / n
+            rx, ry = xx + 0.5 - pa[0], yy + 0.5 - pa[1]
+            along = rx * u[0] + ry * u[1]
+            across = np.abs(rx * u[1] - ry * u[0])
+            m = (along >= -0.5) & (along <= n + 0.5) & (across <= 1.0)
+            paf[:, :, 2 * l][m] += u[0]
+            paf[:, :, 2 * l + 1][m] += u[1]
+            cnt[:, :, l][m] += 1
+    for l in range(14):
+        nz = cnt[:, :, l] > 0
+        paf[:, :, 2 * l][nz] /= cnt[:, :, l][nz]
+        paf[:, :, 2 * l + 1][nz] /= cnt[:, :, l][nz]
+    heat[:, :, 15] = 1.0 - heat[:, :, :15].max(axis=2)
+    heat += rng.uniform(0, noise, heat.shape)
+    paf += rng.normal(0, noise, paf.shape)
+    z += rng.normal(0, noise, z.shape)
+    return (np.clip(heat, 0, 1).astype(np.float32), np.clip(paf, -2, 2).astype(np.float32),
+            np.clip(z, -2, 2).astype(np.float32))
+
+
+def planted_batch(seed, persons_per_frame, **kw):
+    """Stacks planted_maps into NCHW float32 arrays: heat [B,16,h,w], paf [B,28,h,w], z [B,15,h,w]."""
+    hs, ps, zs = [], [], []
+    for i, n in enumerate(persons_per_frame):
+        hm, pf, zz = planted_maps(seed * 1000 + i, n, **kw)
+        hs.append(hm.transpose(2, 0, 1)); ps.append(pf.transpose(2, 0, 1)); zs.append(zz.transpose(2, 0, 1))
+    return np.stack(hs), np.stack(ps), np.stack(zs)
+
+
+def synth_depth(B, H=640, W=480, seed=1234, dtype=np.float16):
+    """depth ~ clip(N(3.0, 0.8), 0, 6) with 4 % zeros, plus a smooth component so
+    the bilinear resize sees structure.  [B, H, W] metres."""
+    rng = np.random.default_rng(seed)
+    base = rng.normal(3.0, 0.8, (B, H // 16 + 1, W // 16 + 1))
+    up = np.repeat(np.repeat(base, 16, axis=1), 16, axis=2)[:, :H, :W]
+    d = np.clip(up + rng.normal(0, 0.05, (B, H, W)), 0, 6)
+    d[rng.random((B, H, W)) < 0.04] = 0
+    return d.astype(dtype)

@@ -1,0 +1,99 @@
+"""``paf_to_pose`` with the reference's signature, computed on the GPU.
+
+Drop-in for tpm/lib/utils/paf_to_pose.py:354-377 (NMS :75-153, find_connected_joints :156-264,
+group_limbs_of_same_person :267-351): takes the HWC float32 network maps of ONE frame and returns
+``(joint_list [N,5] float64, person_to_joint_assoc [P,J+2] float64)`` exactly as the reference
+does -- but the work happens in three HIP kernels (csrc/parse_paf.hip) instead of Python loops over
+scipy/cv2 calls.  For throughput use ``popnet_amd.pipeline.PoseEngine`` (whole batches stay on the
+device); this per-frame wrapper exists for API compatibility and parity tests.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..config import LIMBS
+
+# same module-level names as the reference (paf_to_pose.py:28-30)
+joint_to_limb_heatmap_relationship = [list(l) for l in LIMBS]
+paf_xy_coords_per_limb = np.arange(2 * len(LIMBS)).reshape(-1, 2)
+NUM_LIMBS = len(LIMBS)
+
+
+def make_parse_cfg(config=None, input_size=224, w_org=480, h_org=640, intrinsics=None, depth_mean=3.0, depth_std=2.0):
+    cfg = _lib.ParseCfg()
+    _lib.lib().pn_parse_cfg_default(C.byref(cfg))
+    if config is not None:
+        cfg.thresh_heatmap = float(config.TEST.THRESH_HEATMAP)
+        cfg.thresh_paf = float(config.TEST.THRESH_PAF)
+        cfg.num_intermed_pts = int(config.TEST.NUM_INTERMED_PTS_BETWEEN_KEYPOINTS)
+        cfg.downsample = int(config.MODEL.DOWNSAMPLE)
+        if int(config.MODEL.NUM_KEYPOINTS) != _lib.PN_NUM_JOINTS:
+            raise _lib.PopnetError("parse kernels are built for %d keypoints" % _lib.PN_NUM_JOINTS)
+    cfg.input_size, cfg.w_org, cfg.h_org = int(input_size), int(w_org), int(h_org)
+    if intrinsics is not None:
+        cfg.fx, cfg.fy, cfg.cx, cfg.cy = (float(intrinsics[k]) for k in ('fx', 'fy', 'cx', 'cy'))
+    cfg.depth_mean, cfg.depth_std = float(depth_mean), float(depth_std)
+    return cfg
+
+
+def parse_paf_batch(heat, paf, z, cfg, device=None):
+    """heat [B,J+1,h,w], paf [B,2L,h,w], z [B,L+1,h,w]: float32 CUDA tensors (NCHW).
+    Returns a numpy structured array of B pn_pose_frame records (copied to the host)."""
+    for t, n in ((heat, "heat"), (paf, "paf"), (z, "z")):
+        _lib.require_cuda_tensor(t, n)
+    dev = heat.device
+    B, _, h, w = heat.shape
+    heat, paf, z = heat.contiguous().float(), paf.contiguous().float(), z.contiguous().float()
+    frames = torch.empty((B, _lib.POSE_FRAME_DTYPE.itemsize), device=dev, dtype=torch.uint8)
+    ctx = _lib.Context.for_device(dev.index)
+    ctx.check(_lib.lib().pn_parse_paf(ctx.handle, C.c_void_p(heat.data_ptr()), C.c_void_p(paf.data_ptr()),
+                                      C.c_void_p(z.data_ptr()), B, h, w, C.byref(cfg),
+                                      C.c_void_p(frames.data_ptr()), _lib.current_stream_ptr(dev)), "pn_parse_paf")
+    return frames.cpu().numpy().view(_lib.POSE_FRAME_DTYPE).reshape(B)
+
+
+def frame_joint_list(fr):
+    """pn_pose_frame -> the reference's joint_list ndarray ([N,5]: x, y, score, id, type)."""
+    n = int(fr['n_peaks'])
+    if n == 0:
+        return np.array([])
+    out = np.empty((n, 5), dtype=np.float64)
+    out[:, 0] = fr['peak_x'][:n]
+    out[:, 1] = fr['peak_y'][:n]
+    out[:, 2] = fr['peak_score'][:n]
+    out[:, 3] = np.arange(n)
+    out[:, 4] = fr['peak_type'][:n]
+    return out
+
+
+def frame_assoc(fr):
+    """pn_pose_frame -> the reference's person_to_joint_assoc ndarray ([P, J+2])."""
+    p = int(fr['n_persons'])
+    if p == 0:
+        return np.array([])
+    out = np.empty((p, _lib.PN_NUM_JOINTS + 2), dtype=np.float64)
+    out[:, :_lib.PN_NUM_JOINTS] = fr['person_joint'][:p]
+    out[:, -2] = fr['person_score'][:p]
+    out[:, -1] = fr['person_count'][:p]
+    return out
+
+
+def check_status(fr):
+    if int(fr['status']):
+        raise _lib.PopnetError("pose parse overflow (status=%d): more than %d peaks per joint or %d persons in a frame"
+                               % (int(fr['status']), _lib.PN_MAX_PEAKS_PER_JOINT, _lib.PN_MAX_PERSONS))
+
+
+def paf_to_pose(heatmaps, pafs, config):
+    """heatmaps [h,w,J+1], pafs [h,w,2L]: float32 HWC ndarrays (or CUDA tensors) of one frame."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hm = torch.as_tensor(np.ascontiguousarray(heatmaps) if isinstance(heatmaps, np.ndarray) else heatmaps)
+    pf = torch.as_tensor(np.ascontiguousarray(pafs) if isinstance(pafs, np.ndarray) else pafs)
+    hm = hm.to(dev, torch.float32).permute(2, 0, 1)[None].contiguous()
+    pf = pf.to(dev, torch.float32).permute(2, 0, 1)[None].contiguous()
+    z = torch.zeros((1, NUM_LIMBS + 1, hm.shape[2], hm.shape[3]), device=dev, dtype=torch.float32)
+    fr = parse_paf_batch(hm, pf, z, make_parse_cfg(config))[0]
+    check_status(fr)
+    return frame_joint_list(fr), frame_assoc(fr)

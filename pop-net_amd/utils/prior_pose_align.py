@@ -1,0 +1,55 @@
+"""``parse_prior_pose`` with the reference's signature, computed on the GPU.
+
+Drop-in for tpm/lib/utils/prior_pose_align.py:10-168 (pred_vis=False): same arguments, same
+return structure ``(bboxes[B][n] float32[5], humans[B][n] float32[J,3], visibility[B][n] bool[J])``.
+One HIP workgroup per image decodes only the cells above the objectness threshold, sorts, builds
+the IoU conflict matrix and runs the reference's suppression loop (csrc/parse_yolo.hip).
+Unlike the reference, ``posemaps`` is NOT modified in place (calling the reference twice on the
+same tensor double-applies the decode).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def parse_yolo_batch(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold,
+                     nms_threshold, vis_margin=0):
+    """posemaps: float32 CUDA tensor [B, A*(5+3J), h, w].  Returns host records (structured array)."""
+    _lib.require_cuda_tensor(posemaps, "posemaps")
+    if posemaps.dim() == 3:
+        posemaps = posemaps.unsqueeze(0)
+    pm = posemaps.contiguous().float()
+    B, _, h, w = pm.shape
+    dev = pm.device
+    frames = torch.empty((B, _lib.YOLO_FRAME_DTYPE.itemsize), device=dev, dtype=torch.uint8)
+    flat = [float(v) for a in anchors for v in a]
+    arr = (C.c_float * len(flat))(*flat)
+    ctx = _lib.Context.for_device(dev.index)
+    ctx.check(_lib.lib().pn_parse_yolo(ctx.handle, C.c_void_p(pm.data_ptr()), B, h, w, arr, len(anchors), num_joints,
+                                       int(w_out), int(h_out), float(depth_mean), float(depth_std), float(conf_threshold),
+                                       float(nms_threshold), int(vis_margin), C.c_void_p(frames.data_ptr()),
+                                       _lib.current_stream_ptr(dev)), "pn_parse_yolo")
+    return frames.cpu().numpy().view(_lib.YOLO_FRAME_DTYPE).reshape(B)
+
+
+def parse_prior_pose(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold=0.35,
+                     nms_threshold=0.5, pred_vis=False, vis_margin=0):
+    if pred_vis:
+        raise _lib.PopnetError("pred_vis=True (4J-channel maps) is not part of the MP-3DHP path and is not built")
+    recs = parse_yolo_batch(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold,
+                            nms_threshold, vis_margin)
+    bboxes_out, humans_prior, visibility = [], [], []
+    for fr in recs:
+        if int(fr['status']):
+            raise _lib.PopnetError("yolo decode overflow (status=%d)" % int(fr['status']))
+        n = int(fr['n_det'])
+        if n == 0:
+            bboxes_out.append([]); humans_prior.append([]); visibility.append([])
+            continue
+        bboxes_out.append([fr['bbox'][i].copy() for i in range(n)])
+        humans_prior.append([fr['human'][i].copy() for i in range(n)])
+        visibility.append([fr['visibility'][i].astype(bool) for i in range(n)])
+    return bboxes_out, humans_prior, visibility
