@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Headline benchmark: end-to-end depth-frames/s (480x640 f16 frames -> 3D joints) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One step = one batch of 32 synthetic 480(w)x640(h) depth frames, already resident in HBM, through
+the whole hot path on one GPU: pn_preprocess -> rtpose_light3d forward (bf16 MFMA) -> pose parsing
+-> records copied to pinned host memory.  This is BASELINE.json configs[1].  Weights are seeded
+random with the heat head calibrated to a realistic peak density (pipeline.calibrate_heads); data is
+synthetic (no dataset / checkpoint ships with the reference).
+
+Multi-GPU: weak scaling, every rank runs its own 32-frame batches (frames are independent, no
+collective on the data path) and ONE all-gather of the pose records over RCCL/xGMI closes the timed
+region.  Prints exactly one JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 32
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(engine, depth_host, frames_sample=8):
+    """The oracle (a port of the reference's CPU path: numpy/cv2-restatement pre-proc, torch fp32 CPU
+    forward on all host cores, NumPy parse) timed on a bounded sample of the same workload."""
+    from oracle import nets as onets, parse_paf as oparse, preproc as opre
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in engine.model.state_dict().items()}
+    d = depth_host[:frames_sample]
+    t0 = time.time()
+    x = torch.from_numpy(opre.preprocess_batch(d))
+    t1 = time.time()
+    paf, heat, z = onets.rtpose_light3d_forward(x, sd)
+    t2 = time.time()
+    paf, heat, z = (a.numpy().transpose(0, 2, 3, 1) for a in (paf, heat, z))
+    n_persons = 0
+    for b in range(len(d)):
+        rec = oparse.frame_to_records(heat[b].copy(), paf[b].copy(), z[b].copy())
+        n_persons += len(rec['humans_2d'])
+    t3 = time.time()
+    total = t3 - t0
+    return {"value": round(len(d) / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d of the step's 32 frames, fp32: preproc %.2fs + torch-CPU forward %.2fs (%d threads) + "
+                      "numpy parse %.2fs (1 thread)" % (len(d), t1 - t0, t2 - t1, cores, t3 - t2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import popnet_amd  # noqa: F401
+    from popnet_amd import _lib, synth
+    from popnet_amd.pipeline import PoseEngine
+
+    engine = PoseEngine(precision=args.precision, device=dev, max_batch=BATCH)
+    depth_host = synth.synth_depth(BATCH, 640, 480, seed=1234 + rank)
+    depth = torch.from_numpy(depth_host).to(dev)
+    K, W = args.steps, args.warmup
+    item = _lib.POSE_FRAME_DTYPE.itemsize
+    frames_dev = torch.empty((K, BATCH, item), device=dev, dtype=torch.uint8)
+    frames_host = torch.empty((K, BATCH, item), dtype=torch.uint8, pin_memory=True)
+    gathered = torch.empty((world * K * BATCH, item), device=dev, dtype=torch.uint8) if world > 1 else None
+
+    def step(k):
+        engine.predict(depth, frames_dev[k])
+        frames_host[k].copy_(frames_dev[k], non_blocking=True)
+
+    for i in range(W):
+        step(i % K)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, frames_dev.view(K * BATCH, item))
+    torch.cuda.synchronize()
+
+    L = _lib.lib()
+    L.pn_net_profile_begin(engine.net)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, frames_dev.view(K * BATCH, item))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    conv_ms, other_ms, conv_flops = C.c_double(), C.c_double(), C.c_double()
+    conv_n, other_n = C.c_int64(), C.c_int64()
+    engine.ctx.check(L.pn_net_profile_end(engine.net, C.byref(conv_ms), C.byref(conv_n), C.byref(conv_flops),
+                                          C.byref(other_ms), C.byref(other_n)), "pn_net_profile_end")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        recs = frames_host.numpy().view(_lib.POSE_FRAME_DTYPE).reshape(K, BATCH)
+        total_frames = world * K * BATCH
+        achieved = conv_flops.value / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "depth-frames/sec end-to-end (480x640)", "value": round(total_frames / elapsed, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=32 synthetic 480x640 f16 depth frames per GPU per step, "
+                                   "resize->224^2, rtpose_light3d forward + PAF pose parsing, records D2H",
+                       "frames_per_step_per_gpu": BATCH, "input": "480x640 f16", "network_input": "224x224",
+                       "weights": "seeded random, heat head calibrated (pipeline.calibrate_heads)",
+                       "parallelism": "frames sharded x%d, one all-gather of records" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all %d launches/forward)" % (conv_n.value // max(K, 1)),
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
+                         "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4),
+                         "traffic": traffic,
+                         "avg_launch_us": round(conv_ms.value * 1e3 / max(conv_n.value, 1), 3),
+                         "flops_per_launch": round(conv_flops.value / max(conv_n.value, 1), 1),
+                         "conv_ms_per_step": round(conv_ms.value / K, 4), "stem_pool_ms_per_step": round(other_ms.value / K, 4)},
+            "frame_stats": {"mean_peaks": round(float(recs['n_peaks'].mean()), 2),
+                            "mean_persons": round(float(recs['n_persons'].mean()), 3),
+                            "overflow_frames": int((recs['status'] != 0).sum())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(engine, depth_host)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,14 @@ int pn_net_read_activation(pn_net *net, const char *name, int B, float *host_out
 int pn_net_copy_activation(pn_net *net, const char *name, int B, float *dev_out, void *hip_stream);
 /* Algorithmic FLOPs (2*MAC, convolutions only) of one frame through the finalized net. */
 double pn_net_flops_per_frame(pn_net *net);
+/* Measurement hooks: between begin and end every kernel launch of pn_*_forward is bracketed by
+ * HIP events recorded on the caller's stream.  end() waits for them and returns the summed
+ * durations: conv_* = the MFMA convolution launches (with the algorithmic FLOPs they covered),
+ * other_* = stem + pooling launches.  Event pairs are recycled; nothing is allocated per call once
+ * the first profiled forward has run. */
+int pn_net_profile_begin(pn_net *net);
+int pn_net_profile_end(pn_net *net, double *conv_ms, int64_t *conv_launches, double *conv_flops,
+                       double *other_ms, int64_t *other_launches);
 
 /* ---- Open-Pose+ parsing ---------------------------------------------------------------------
  * Replaces, per frame, paf_to_pose + paf_to_human_list + the depth read-out / rescale /

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "pn_net_read_activation": (_i, [_vp, C.c_char_p, _i, _vp, _sz, _vp]),
     "pn_net_copy_activation": (_i, [_vp, C.c_char_p, _i, _vp, _vp]),
     "pn_net_flops_per_frame": (_d, [_vp]),
+    "pn_net_profile_begin": (_i, [_vp]),
+    "pn_net_profile_end": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_int64), C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_int64)]),
     "pn_parse_cfg_default": (None, [C.POINTER(ParseCfg)]),
     "pn_parse_paf": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),

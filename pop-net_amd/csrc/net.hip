@@ -44,7 +44,7 @@ struct ConvSpec {
     int nchw_slot = -1;       // index into pn_net::nchw_ptr or -1
     int cout = 0;
     // derived
-    int cfg = 0, pitch = 0, R = 0, cin_chunks = 0;
+    int cfg = 0, pitch = 0, R = 0, Wt = 0, cin_chunks = 0;
     void *wpack = nullptr;
     float *bias = nullptr;
     double flops = 0;
@@ -90,6 +90,11 @@ struct pn_net {
     std::map<std::string, std::pair<int, std::pair<int, int>>> named;   // name -> (buf, (coff, C))
     double flops_per_frame = 0;
     int out_h = 0, out_w = 0;
+    // optional per-launch HIP-event timing (bench.py's live roofline measurement)
+    bool profiling = false;
+    struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+    std::vector<ProfRec> prof;
+    size_t prof_used = 0;
 
     size_t esize() const { return prec == PN_PREC_BF16 ? 2 : 4; }
 };
@@ -219,10 +224,12 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const Buf &ib = n->bufs[cs.in_buf];
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
     const int BP = cs.cfg == PN_CFG_C128 ? 112 : 128;
-    if (Wo > BP) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: output width %d exceeds the %d-pixel block tile", cs.w.c_str(), Wo, BP);
-    cs.R = std::min(Ho, BP / Wo);
-    cs.pitch = pick_pitch((Wo - 1) * cs.stride + ks);
-    if (cs.pitch < 0) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo width %d has no pitch class", cs.w.c_str(), (Wo - 1) * cs.stride + ks);
+    // a block owns R full rows when they fit its pixel tile, else one row cut into equal segments
+    const int segs = (Wo + BP - 1) / BP;
+    cs.Wt = (Wo + segs - 1) / segs;
+    cs.R = std::max(1, std::min(Ho, BP / cs.Wt));
+    cs.pitch = pick_pitch((cs.Wt - 1) * cs.stride + ks);
+    if (cs.pitch < 0) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo width %d has no pitch class", cs.w.c_str(), (cs.Wt - 1) * cs.stride + ks);
     cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
     if (cs.out_buf >= 0) {
         const Buf &ob = n->bufs[cs.out_buf];
@@ -254,7 +261,7 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         const ConvSpec &a = n->convs[ids[i]];
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
-            if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.cfg == a.cfg && b.R == a.R) {
+            if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.cfg == a.cfg && b.R == a.R && b.Wt == a.Wt) {
                 st.conv_ids.push_back(ids[j]);
                 used[j] = true;
             }
@@ -460,7 +467,9 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.act = cs.act;
             P.yolo_naf = 5 + 3 * n->num_parts;
             P.R = cs.R;
-            P.tiles_per_img = (P.Ho + cs.R - 1) / cs.R;
+            P.Wt = cs.Wt;
+            P.tiles_x = (P.Wo + cs.Wt - 1) / cs.Wt;
+            P.tiles_per_img = ((P.Ho + cs.R - 1) / cs.R) * P.tiles_x;
             P.cout_blocks = (cs.cout + BC - 1) / BC;
             P.nblocks = B * P.tiles_per_img * P.cout_blocks;
             P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
@@ -491,6 +500,21 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         if (int rc = refresh_problems(n, B, stream)) return rc;
     for (auto &st : n->steps) {
         int rc = PN_OK;
+        pn_net::ProfRec *pr = nullptr;
+        if (n->profiling) {
+            if (n->prof_used == n->prof.size()) {
+                pn_net::ProfRec r;
+                PN_HIP_CHECK(ctx, hipEventCreate(&r.a));
+                PN_HIP_CHECK(ctx, hipEventCreate(&r.b));
+                n->prof.push_back(r);
+            }
+            pr = &n->prof[n->prof_used++];
+            pr->kind = (int)st.type;
+            pr->flops = 0;
+            if (st.type == Step::CONV)
+                for (int id : st.conv_ids) pr->flops += n->convs[id].flops * B;
+            PN_HIP_CHECK(ctx, hipEventRecord(pr->a, stream));
+        }
         if (st.type == Step::STEM) {
             const Buf &ob = n->bufs[st.out_buf];
             rc = pn_launch_stem(ctx, n->prec, x, st.stem_w, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, stream);
@@ -501,6 +525,7 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
             rc = pn_launch_conv(ctx, st.launch, stream);
         }
         if (rc) return rc;
+        if (pr) PN_HIP_CHECK(ctx, hipEventRecord(pr->b, stream));
     }
     return PN_OK;
 }
@@ -528,6 +553,7 @@ pn_net *pn_net_create(pn_ctx *ctx, int kind, int num_parts, int a, int input_dim
 void pn_net_destroy(pn_net *n) {
     if (!n) return;
     for (void *p : n->dev_allocs) (void)hipFree(p);
+    for (auto &r : n->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     delete n;
 }
 
@@ -615,5 +641,35 @@ int pn_net_read_activation(pn_net *n, const char *name, int B, float *host_out, 
 }
 
 double pn_net_flops_per_frame(pn_net *n) { return n ? n->flops_per_frame : 0.0; }
+
+int pn_net_profile_begin(pn_net *n) {
+    if (!n) return PN_ERR_INVALID;
+    n->profiling = true;
+    n->prof_used = 0;
+    return PN_OK;
+}
+
+int pn_net_profile_end(pn_net *n, double *conv_ms, int64_t *conv_launches, double *conv_flops, double *other_ms,
+                       int64_t *other_launches) {
+    if (!n) return PN_ERR_INVALID;
+    pn_ctx *ctx = n->ctx;
+    n->profiling = false;
+    double cm = 0, om = 0, cf = 0;
+    int64_t cl = 0, ol = 0;
+    for (size_t i = 0; i < n->prof_used; ++i) {
+        PN_HIP_CHECK(ctx, hipEventSynchronize(n->prof[i].b));
+        float ms = 0.f;
+        PN_HIP_CHECK(ctx, hipEventElapsedTime(&ms, n->prof[i].a, n->prof[i].b));
+        if (n->prof[i].kind == (int)Step::CONV) { cm += ms; cf += n->prof[i].flops; ++cl; }
+        else { om += ms; ++ol; }
+    }
+    n->prof_used = 0;
+    if (conv_ms) *conv_ms = cm;
+    if (conv_launches) *conv_launches = cl;
+    if (conv_flops) *conv_flops = cf;
+    if (other_ms) *other_ms = om;
+    if (other_launches) *other_launches = ol;
+    return PN_OK;
+}
 
 }  // extern "C"

@@ -56,7 +56,8 @@ struct ConvProblem {
     int act;
     int yolo_naf;          // channels per anchor for PN_ACT_YOLO (5 + 3J)
     int R;                 // output rows per block
-    int tiles_per_img;     // ceil(Ho / R)
+    int Wt, tiles_x;       // output columns per block, ceil(Wo / Wt)
+    int tiles_per_img;     // ceil(Ho / R) * tiles_x
     int cout_blocks;       // ceil(cout / (WC*CT*16))
     int nblocks;           // B * tiles_per_img * cout_blocks
     int ksteps;            // cin_chunks * KS*KS * 2   (k32 steps per cout tile in wpack)

@@ -1,0 +1,338 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI of libpopnet_hip.so, against
+  (1) the golden vectors produced by the reference itself (tests/golden),
+  (2) the oracle on seeded inputs the oracle finishes in seconds,
+  (3) size-independent properties at BASELINE's full batch size.
+Bit-exact for every index / integer / byte result and for all float results of the parse path
+(same operation order as the oracle); fp32 forward within 2e-4 absolute of the fp32 CPU reference
+(different summation order), bf16 forward within the tolerance stated in each test.
+`/root/reference` is never touched here."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (PAFPROCESS_CASES, YOLO_ANCHORS, all_parse_case_names, coco_case, humans_to_array,
+                     parse_case_inputs, state_dict_from_keys, yolo_maps)
+from popnet_amd import _lib, synth
+from popnet_amd.config import default_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded_native():
+    assert _lib.lib() is not None        # raises when the extension is missing: no silent fallback
+
+
+# ---------------------------------------------------------------------------------------------
+# pre-processing
+# ---------------------------------------------------------------------------------------------
+def _preprocess(gpu, frames, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(frames)).to(gpu)
+    B, H, W = t.shape
+    out = torch.empty((B, 1, 224, 224), device=gpu)
+    ctx = _lib.Context.for_device(0)
+    ctx.check(_lib.lib().pn_preprocess(ctx.handle, C.c_void_p(t.data_ptr()), dtype, B, H, W, C.c_void_p(out.data_ptr()),
+                                       224, 6.0, 3.0, 2.0, _lib.current_stream_ptr(gpu)), "pn_preprocess")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_preprocess_bit_exact_vs_reference_golden(gpu, golden):
+    _loaded_native()
+    g = golden.forward
+    x0 = _preprocess(gpu, g["sample_frame"][None], _lib.PN_DEPTH_F16)          # 240x320 ITOP frame of the reference
+    x1 = _preprocess(gpu, synth.synth_depth(1, 640, 480, seed=3), _lib.PN_DEPTH_F16)
+    assert np.array_equal(x0[0], g["x"][0]) and np.array_equal(x1[0], g["x"][1])
+
+
+def test_preprocess_f32_edge_values(gpu):
+    from oracle import preproc
+    rng = np.random.default_rng(9)
+    d = rng.uniform(-1, 8, (3, 97, 131)).astype(np.float32)       # ragged size, values outside [0, depth_max]
+    got = _preprocess(gpu, d, _lib.PN_DEPTH_F32)
+    assert np.array_equal(got, preproc.preprocess_batch(d))
+    assert got.min() >= -1.5 and got.max() <= 1.5
+
+
+# ---------------------------------------------------------------------------------------------
+# network forward
+# ---------------------------------------------------------------------------------------------
+def _rtpose(golden, prec, seed=0):
+    from popnet_amd.network.rtpose_light3d import rtpose_light3d
+    m = rtpose_light3d(15, 14, 2, input_dim=1).eval()
+    m.load_state_dict(state_dict_from_keys(golden.keys["rtpose_light3d"], seed=seed))
+    m.precision = prec
+    return m
+
+
+def test_rtpose_forward_fp32_vs_reference_golden(gpu, golden):
+    g = golden.forward
+    m = _rtpose(golden, "fp32")
+    (paf, heat, z), saved = m(torch.from_numpy(g["x"]).to(gpu))
+    torch.cuda.synchronize()
+    for got, key in ((paf, "rt_paf"), (heat, "rt_heat"), (z, "rt_z")):
+        assert np.abs(got.cpu().numpy() - g[key]).max() < 2e-4, key
+    assert np.abs(m.stem_features(2).cpu().numpy()[:, ::8, ::2, ::2] - g["rt_feat"]).max() < 2e-4
+    for got, key in ((saved[0], "rt_paf1"), (saved[1], "rt_heat1"), (saved[2], "rt_z1")):
+        assert np.abs(got.cpu().numpy()[:, :, ::4, ::4] - g[key]).max() < 2e-4, key
+    assert saved[3] is paf and saved[4] is heat and saved[5] is z
+    assert abs(m.flops_per_frame() / 1e9 - 13.343) < 0.01
+
+
+def test_rtpose_forward_bf16_tolerance(gpu, golden):
+    """bf16 storage + bf16 MFMA, fp32 accumulate: maps within 0.15 absolute (range: paf/z (-2,2),
+    heat (0,1)) and 0.02 mean absolute of the fp32 reference on seeded O(1)-scale weights."""
+    g = golden.forward
+    m = _rtpose(golden, "bf16")
+    (paf, heat, z), _ = m(torch.from_numpy(g["x"]).to(gpu))
+    torch.cuda.synchronize()
+    for got, key in ((paf, "rt_paf"), (heat, "rt_heat"), (z, "rt_z")):
+        d = np.abs(got.cpu().numpy() - g[key])
+        assert d.max() < 0.15 and d.mean() < 0.02, (key, d.max(), d.mean())
+
+
+def test_yolo_forward_fp32_vs_reference_golden(gpu, golden):
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    g = golden.forward
+    m = YoloPoseNet(15, input_dim=1).eval()
+    m.load_state_dict(state_dict_from_keys(golden.keys["yolo_posenet"], seed=1))
+    m.precision = "fp32"
+    out = m(torch.from_numpy(g["x"]).to(gpu))
+    torch.cuda.synchronize()
+    # activations reach |x| ~ 150 with the seeded weights; tolerance is relative to that scale
+    feat = m.backbone_features(2).cpu().numpy()[:, ::8, ::2, ::2]
+    assert np.abs(feat - g["yolo_feat"]).max() < 1e-5 * np.abs(g["yolo_feat"]).max() + 1e-4
+    assert np.abs(out.cpu().numpy() - g["yolo_out"]).max() < 2e-3
+    assert abs(m.flops_per_frame() / 1e9 - 8.691) < 0.01
+
+
+def test_forward_batch_invariance_and_ragged_batches(gpu, golden):
+    """Frames are independent (eval-mode BN): a frame's maps must not depend on what else is in the
+    batch or on the batch size (exercises partial tiles / cached problem descriptors)."""
+    m = _rtpose(golden, "fp32")
+    x = torch.from_numpy(np.random.default_rng(4).normal(0, 1, (5, 1, 224, 224)).astype(np.float32)).to(gpu)
+    (p5, h5, z5), _ = m(x)
+    (p1, h1, z1), _ = m(x[3:4])
+    (p2, h2, z2), _ = m(x[[4, 0]])
+    torch.cuda.synchronize()
+    assert torch.equal(p5[3:4], p1) and torch.equal(h5[3:4], h1) and torch.equal(z5[3:4], z1)
+    assert torch.equal(p5[[4, 0]], p2) and torch.equal(z5[[4, 0]], z2)
+
+
+def test_forward_other_input_sizes(gpu, golden):
+    """Fully convolutional: the ITOP-native 240x320 frame (pitch classes 64 / 32) against the oracle."""
+    from oracle import nets
+    m = _rtpose(golden, "fp32")
+    x = torch.from_numpy(np.random.default_rng(5).normal(0, 1, (2, 1, 240, 320)).astype(np.float32))
+    sd = state_dict_from_keys(golden.keys["rtpose_light3d"], seed=0)
+    rp, rh, rz = nets.rtpose_light3d_forward(x, sd)
+    (p, h, z), _ = m(x.to(gpu))
+    torch.cuda.synchronize()
+    assert p.shape == (2, 28, 30, 40)
+    for got, ref in ((p, rp), (h, rh), (z, rz)):
+        assert (got.cpu() - ref).abs().max() < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# Open-Pose+ parsing
+# ---------------------------------------------------------------------------------------------
+def _parse(gpu, heat_hwc, paf_hwc, z_hwc):
+    from popnet_amd.utils.paf_to_pose import make_parse_cfg, parse_paf_batch
+    t = [torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))[None].to(gpu) for a in (heat_hwc, paf_hwc, z_hwc)]
+    return parse_paf_batch(t[0], t[1], t[2], make_parse_cfg(default_cfg()))[0]
+
+
+@pytest.mark.parametrize("name", all_parse_case_names())
+def test_parse_bit_exact_vs_reference_golden(gpu, golden, name):
+    from popnet_amd.utils.paf_to_pose import frame_assoc, frame_joint_list
+    heat, paf, z = parse_case_inputs(golden, name)
+    fr = _parse(gpu, heat, paf, z)
+    g = golden.parse
+    assert int(fr["status"]) == 0
+    jl = frame_joint_list(fr).reshape(-1, 5)
+    assoc = frame_assoc(fr).reshape(-1, 17)
+    assert np.array_equal(jl, g["%s_joint_list" % name])                     # x, y, refined score, id, type
+    assert assoc.shape == g["%s_assoc" % name].shape
+    assert np.array_equal(assoc[:, :15], g["%s_assoc" % name][:, :15])       # person assignment indices
+    assert np.array_equal(assoc[:, 16], g["%s_assoc" % name][:, 16])
+    assert np.allclose(assoc[:, 15], g["%s_assoc" % name][:, 15], rtol=1e-12, atol=1e-12)   # BLAS-vs-plain 1 ulp
+    n = assoc.shape[0]
+    assert np.array_equal(fr["joints_3d"][:n, :, 2], g["%s_depths" % name])  # heat-weighted depth read-out
+    assert np.array_equal(fr["part_conf"][:n], g["%s_conf" % name])
+
+
+def test_paf_to_pose_api_returns_reference_structures(gpu, golden):
+    """The per-frame drop-in: same call as tpm/lib/utils/paf_to_pose.py:354, same return types."""
+    from popnet_amd.utils.paf_to_pose import paf_to_pose
+    from popnet_amd.utils.common import paf_to_human_list, retrieve_depth_heat_weighted
+    heat, paf, z = parse_case_inputs(golden, "planted_s4_p3")
+    joint_list, assoc = paf_to_pose(heat, paf, default_cfg())
+    assert joint_list.dtype == np.float64 and assoc.dtype == np.float64
+    assert np.array_equal(joint_list, golden.parse["planted_s4_p3_joint_list"])
+    humans, vis, conf = paf_to_human_list(joint_list, assoc)
+    assert len(humans) == len(golden.parse["planted_s4_p3_assoc"]) and len(humans[0]) == 15 and len(vis[0]) == 15
+    # empty frame -> empty arrays like the reference
+    jl0, as0 = paf_to_pose(np.zeros((28, 28, 16), np.float32), np.zeros((28, 28, 28), np.float32), default_cfg())
+    assert jl0.size == 0 and as0.size == 0
+    # stand-alone depth read-out, including the in-place clamp of negative heat values
+    depthmap = (z[:, :, 0] * 2 + 3).astype(np.float32)
+    hm = heat[:, :, 0].copy()
+    hm[3, 3] = -0.5
+    from oracle import parse_paf as O
+    hm_ref = hm.copy()
+    want = O.retrieve_depth_heat_weighted([3, 4], depthmap, hm_ref, 1)
+    got = retrieve_depth_heat_weighted([3, 4], depthmap, hm, 1)
+    assert got == want and hm[3, 3] == 0.0 and np.array_equal(hm, hm_ref)
+    assert retrieve_depth_heat_weighted([0, 27], depthmap, hm, 1) == O.retrieve_depth_heat_weighted([0, 27], depthmap, hm_ref, 1)
+
+
+def test_parse_full_batch_matches_oracle_and_is_batch_invariant(gpu):
+    """BASELINE batch (32 frames, 0..8 persons): every frame equals the oracle, and equals the same
+    frame parsed alone (no cross-frame state in the workspace)."""
+    from oracle import parse_paf as O
+    from popnet_amd.utils.paf_to_pose import frame_assoc, frame_joint_list, make_parse_cfg, parse_paf_batch
+    persons = [(i * 5) % 9 for i in range(32)]
+    heat, paf, z = synth.planted_batch(77, persons)
+    cfg = make_parse_cfg(default_cfg())
+    th, tp, tz = (torch.from_numpy(a).to(gpu) for a in (heat, paf, z))
+    frames = parse_paf_batch(th, tp, tz, cfg)
+    again = parse_paf_batch(th, tp, tz, cfg)
+
+    def valid(fr):          # the defined part of a record (slots past n_peaks / n_persons are unspecified)
+        n, p = int(fr["n_peaks"]), int(fr["n_persons"])
+        return (n, p, int(fr["status"]), fr["peak_x"][:n].tobytes(), fr["peak_y"][:n].tobytes(), fr["peak_score"][:n].tobytes(),
+                fr["peak_type"][:n].tobytes(), fr["person_joint"][:p].tobytes(), fr["person_score"][:p].tobytes(),
+                fr["person_count"][:p].tobytes(), fr["joints_2d"][:p].tobytes(), fr["joints_3d"][:p].tobytes(),
+                fr["part_conf"][:p].tobytes())
+
+    for b in range(32):
+        assert valid(frames[b]) == valid(again[b])                           # idempotent / deterministic
+    for b in (0, 5, 13, 31):
+        alone = parse_paf_batch(th[b:b + 1], tp[b:b + 1], tz[b:b + 1], cfg)[0]
+        assert valid(alone) == valid(frames[b])
+    for b in range(32):
+        rec = O.frame_to_records(heat[b].transpose(1, 2, 0).copy(), paf[b].transpose(1, 2, 0).copy(), z[b].transpose(1, 2, 0).copy())
+        fr = frames[b]
+        assert int(fr["status"]) == 0
+        jl, assoc = frame_joint_list(fr), frame_assoc(fr)
+        assert jl.shape == np.asarray(rec["joint_list"]).shape and (jl.size == 0 or np.array_equal(jl, rec["joint_list"]))
+        assert assoc.shape == np.asarray(rec["assoc"]).shape
+        if assoc.size:
+            n = assoc.shape[0]
+            assert np.array_equal(assoc[:, :15], rec["assoc"][:, :15])
+            assert np.array_equal(fr["joints_2d"][:n], np.array(rec["humans_2d"]))
+            assert np.array_equal(fr["joints_3d"][:n], np.array(rec["humans_3d"]))
+            assert np.array_equal(fr["part_conf"][:n], np.array(rec["conf"]))
+
+
+def test_parse_overflow_is_flagged_not_silent(gpu):
+    """A constant heat map is one giant plateau: every cell is a peak.  The record must carry the
+    overflow status and the per-frame API must raise."""
+    from popnet_amd.utils.paf_to_pose import paf_to_pose
+    heat = np.full((28, 28, 16), 0.5, np.float32)
+    fr = _parse(gpu, heat, np.zeros((28, 28, 28), np.float32), np.zeros((28, 28, 15), np.float32))
+    assert int(fr["status"]) & _lib.PN_FRAME_OVERFLOW_PEAKS
+    with pytest.raises(_lib.PopnetError, match="overflow"):
+        paf_to_pose(heat, np.zeros((28, 28, 28), np.float32), default_cfg())
+
+
+# ---------------------------------------------------------------------------------------------
+# Yolo-Pose+ decode
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_yolo_decode_bit_exact_vs_reference_golden(gpu, golden, seed):
+    from popnet_amd.utils.prior_pose_align import parse_prior_pose
+    pm = yolo_maps(seed, clusters=seed != 33)
+    t = torch.from_numpy(pm.copy()).to(gpu)
+    b, h, v = parse_prior_pose(t, YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    assert torch.equal(t.cpu(), torch.from_numpy(pm))                        # input not modified
+    for i in range(pm.shape[0]):
+        assert np.array_equal(np.array(b[i], np.float32).reshape(-1, 5), golden.yolo["s%d_%d_bbox" % (seed, i)])
+        assert np.array_equal(np.array(h[i], np.float32).reshape(-1, 15, 3), golden.yolo["s%d_%d_human" % (seed, i)])
+        assert np.array_equal(np.array(v[i], bool).reshape(-1, 15), golden.yolo["s%d_%d_vis" % (seed, i)])
+
+
+def test_yolo_decode_dense_batch_vs_oracle(gpu):
+    from oracle import parse_yolo as O
+    from popnet_amd.utils.prior_pose_align import parse_prior_pose
+    rng = np.random.default_rng(8)
+    pm = rng.uniform(-1, 1, (32, 100, 14, 14)).astype(np.float32)
+    pm[:, 4] = rng.uniform(0, 0.58, (32, 14, 14))
+    pm[:, 54] = rng.uniform(0, 0.54, (32, 14, 14))
+    pm[:, 2:4] = rng.uniform(0.5, 2, (32, 2, 14, 14))
+    pm[:, 52:54] = rng.uniform(0.5, 2, (32, 2, 14, 14))
+    rb, rh, rv = O.parse_prior_pose(pm.copy(), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    b, h, v = parse_prior_pose(torch.from_numpy(pm).to(gpu), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    for i in range(32):
+        assert len(b[i]) == len(rb[i])
+        if len(b[i]):
+            assert np.array_equal(np.array(b[i]), np.array(rb[i]))
+            assert np.array_equal(np.array(h[i]), np.array(rh[i]))
+            assert np.array_equal(np.array(v[i]), np.array(rv[i]))
+
+
+# ---------------------------------------------------------------------------------------------
+# legacy pafprocess plug-in ABI
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,P", PAFPROCESS_CASES)
+def test_pafprocess_abi_vs_compiled_reference_golden(gpu, golden, seed, P):
+    from popnet_amd import pafprocess
+    pk, heat, paf = coco_case(seed, P)
+    got = humans_to_array(pafprocess.run(pk, heat, paf))
+    assert np.array_equal(got, golden.pafprocess["s%d_p%d" % (seed, P)])
+
+
+def test_pafprocess_rejects_out_of_range_peaks(gpu):
+    from popnet_amd import pafprocess
+    pk = np.array([[[500, 3, 0.9, 0, 1]]], np.float32)        # x outside the 216-wide map: the reference reads out of bounds
+    with pytest.raises(_lib.PopnetError):
+        pafprocess.process_paf(pk, np.zeros((184, 216, 19), np.float32), np.zeros((184, 216, 38), np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+# whole path
+# ---------------------------------------------------------------------------------------------
+def test_end_to_end_vs_reference_eval_script(gpu, golden):
+    """Depth frames -> PoseEngine (fp32 parity mode) == eval_data.json of the reference's own
+    evaluation script on the same frames and weights: person assignment / visibility exact, 2D exact,
+    3D joints within 1e-3 m (north_star tolerance)."""
+    from popnet_amd.pipeline import PoseEngine
+    s = golden.script
+    sd = state_dict_from_keys(golden.keys["rtpose_light3d"], seed=s["weight_seed"])
+    sd["model2_2.12.bias"][:15] += torch.tensor(s["heat_bias_shift"])
+    eng = PoseEngine(precision="fp32", state_dict=sd, device=gpu, max_batch=2)
+    frames = synth.synth_depth(2, 640, 480, seed=s["depth_seed"])
+    recs = eng.predict_host(torch.from_numpy(frames).to(gpu))
+    for b in range(2):
+        fr = recs[b]
+        n = int(fr["n_persons"])
+        assert n == len(s["human_pred_set_2d"][b]) and int(fr["status"]) == 0
+        vis = (fr["person_joint"][:n] >= 0).astype(int)
+        assert vis.tolist() == s["human_pred_set_visibility"][b]
+        assert np.allclose(fr["joints_2d"][:n], np.array(s["human_pred_set_2d"][b]), atol=1e-9)
+        assert np.abs(fr["joints_3d"][:n] - np.array(s["human_pred_set_3d"][b])).max() < 1e-3
+        assert np.allclose(fr["part_conf"][:n], np.array(s["human_pred_set_part_conf"][b]), atol=1e-4)
+
+
+def test_engine_bf16_full_batch_runs_and_parse_is_self_consistent(gpu):
+    """BASELINE configs[1] (32 frames, bf16): the records must equal the ORACLE parse of the maps the
+    HIP forward produced -- i.e. whatever bf16 does to the maps, the parse stage stays bit-exact."""
+    from oracle import parse_paf as O
+    from popnet_amd.pipeline import PoseEngine, records_to_numpy
+    from popnet_amd.utils.paf_to_pose import frame_assoc, frame_joint_list
+    eng = PoseEngine(precision="bf16", device=gpu, max_batch=32)
+    depth = torch.from_numpy(synth.synth_depth(32, 640, 480, seed=5)).to(gpu)
+    recs = records_to_numpy(eng.predict(depth))
+    torch.cuda.synchronize()
+    hp, hh, hz = (t.cpu().numpy().transpose(0, 2, 3, 1) for t in (eng.paf, eng.heat, eng.z))
+    assert np.isfinite(hp).all() and np.isfinite(hh).all() and np.isfinite(hz).all()
+    for b in range(0, 32, 5):
+        rec = O.frame_to_records(hh[b].copy(), hp[b].copy(), hz[b].copy())
+        jl, assoc = frame_joint_list(recs[b]), frame_assoc(recs[b])
+        assert int(recs[b]["status"]) == 0
+        assert jl.shape == np.asarray(rec["joint_list"]).shape and (jl.size == 0 or np.array_equal(jl, rec["joint_list"]))
+        assert assoc.shape == np.asarray(rec["assoc"]).shape
+        if assoc.size:
+            assert np.array_equal(assoc[:, :15], rec["assoc"][:, :15])
+            assert np.array_equal(recs[b]["joints_3d"][:assoc.shape[0]], np.array(rec["humans_3d"]))
