@@ -33,3 +33,12 @@ int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
     return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "no conv kernel for prec=%d ks=%d stride=%d pitch=%d cfg=%d", L.prec, L.ks,
                         L.stride, L.pitch, L.cfg);
 }
+
+// host mirror of StageCfg (conv_mfma_kernel.h): largest halo tile (pixels) the register-prefetched
+// staging path of this instantiation can hold; 0 = that instantiation stages with the plain loop.
+int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch) {
+    const int maxpx = stride != 1 ? 0 : (ks == 1 ? 128 : (pitch <= 32 ? 192 : (pitch <= 64 ? 288 : 360)));
+    const int nch = prec == PN_PREC_BF16 ? 8 : 16;
+    const int raw = (maxpx * nch + 255) / 256;
+    return raw <= 12 ? maxpx : 0;
+}

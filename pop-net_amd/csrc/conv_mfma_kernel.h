@@ -29,6 +29,13 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// Pointers read out of the ConvProblem record are "generic" to the compiler, which then emits flat_*
+// memory ops (they tick vmcnt AND lgkmcnt and can only be waited for with 0/0, serialising against
+// the LDS pipeline).  Everything that touches HBM goes through explicit global-address-space pointers.
+#define PN_GLOBAL __attribute__((address_space(1)))
+typedef const PN_GLOBAL char *gcptr;
+typedef PN_GLOBAL char *gptr;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: loadable through address-space pointers
 
 template <int PREC> struct Elem;
 template <> struct Elem<PN_PREC_BF16> {
@@ -72,16 +79,16 @@ __device__ __forceinline__ float pn_activate(float v, int act, int co, int naf) 
     }
 }
 
-template <int PREC> __device__ __forceinline__ typename Elem<PREC>::Frag load_a_frag(const char *p);
-template <> __device__ __forceinline__ Elem<PN_PREC_BF16>::Frag load_a_frag<PN_PREC_BF16>(const char *p) {
+template <int PREC> __device__ __forceinline__ typename Elem<PREC>::Frag load_a_frag(gcptr p);
+template <> __device__ __forceinline__ Elem<PN_PREC_BF16>::Frag load_a_frag<PN_PREC_BF16>(gcptr p) {
     Elem<PN_PREC_BF16>::Frag f;
-    f.v = *reinterpret_cast<const bf16x8 *>(p);
+    f.v = *reinterpret_cast<const PN_GLOBAL bf16x8 *>(p);
     return f;
 }
-template <> __device__ __forceinline__ Elem<PN_PREC_F32>::Frag load_a_frag<PN_PREC_F32>(const char *p) {
+template <> __device__ __forceinline__ Elem<PN_PREC_F32>::Frag load_a_frag<PN_PREC_F32>(gcptr p) {
     Elem<PN_PREC_F32>::Frag f;   // packed as [half][lane][4 floats]: both halves lane-contiguous
-    f.lo = *reinterpret_cast<const f32x4 *>(p);
-    f.hi = *reinterpret_cast<const f32x4 *>(p + 1024);
+    f.lo = *reinterpret_cast<const PN_GLOBAL f32x4 *>(p);
+    f.hi = *reinterpret_cast<const PN_GLOBAL f32x4 *>(p + 1024);
     return f;
 }
 
@@ -114,18 +121,30 @@ __device__ __forceinline__ f32x4 mma(const Elem<PN_PREC_F32>::Frag &a, const Ele
     return c;
 }
 
-__device__ __forceinline__ void store4(__bf16 *p, const float v[4]) {
+__device__ __forceinline__ void store4(PN_GLOBAL __bf16 *p, const float v[4]) {
     bf16x4 o;
     o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-    *reinterpret_cast<bf16x4 *>(p) = o;
+    *reinterpret_cast<PN_GLOBAL bf16x4 *>(p) = o;
 }
-__device__ __forceinline__ void store4(float *p, const float v[4]) {
+__device__ __forceinline__ void store4(PN_GLOBAL float *p, const float v[4]) {
     f32x4 o = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4 *>(p) = o;
+    *reinterpret_cast<PN_GLOBAL f32x4 *>(p) = o;
 }
 
+// Register-prefetched halo staging: MAXST = 16-B pieces per thread needed to hold the largest halo
+// tile of this geometry (pn_conv_stage_maxpx is the host-side mirror used when R is chosen);
+// 0 = too many registers, stage with the plain load->store loop instead.
+constexpr int pn_stage_maxpx_c(int ks, int stride, int pitch) {
+    return stride != 1 ? 0 : (ks == 1 ? 128 : (pitch <= 32 ? 192 : (pitch <= 64 ? 288 : 360)));
+}
+template <int PREC, int KS, int STRIDE, int PITCH> struct StageCfg {
+    static constexpr int NCH = Elem<PREC>::PIXB / 16;
+    static constexpr int RAW = (pn_stage_maxpx_c(KS, STRIDE, PITCH) * NCH + 255) / 256;
+    static constexpr int MAXST = RAW <= 12 ? RAW : 0;
+};
+
 template <int PREC, int KS, int STRIDE, int PITCH, int CFG>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvProblem *__restrict__ probs) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__restrict__ probs) {
     typedef Elem<PREC> E;
     typedef typename E::T T;
     typedef typename E::Frag Frag;
@@ -137,8 +156,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvProblem *__res
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const ConvProblem &P = probs[blockIdx.y];
-    const int bx = blockIdx.x;
-    if (bx >= P.nblocks) return;
+    if ((int)blockIdx.x >= P.nblocks) return;
+    // XCD-aware remap (speed only): hardware deals consecutive block ids round-robin over the 8
+    // XCDs; give each XCD a contiguous range of logical blocks so that blocks sharing an input
+    // halo / a weight slice hit the same L2.  Bijective for any nblocks.
+    int bx;
+    {
+        const int nb = P.nblocks, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qq = nb >> 3, rr = nb & 7;
+        bx = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -187,107 +214,221 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvProblem *__res
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ctile0 = (cb * WC + wc) * CT;
-    const char *wptr[CT];
+    gcptr wptr[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
-        wptr[ct] = (const char *)P.wpack + (size_t)(ctile0 + ct) * P.ksteps * FRAGB + lane * 16;
+        wptr[ct] = (gcptr)P.wpack + (size_t)(ctile0 + ct) * P.ksteps * FRAGB + lane * 16;
 
-    Frag a_cur[CT], a_nxt[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) a_nxt[ct] = load_a_frag<PREC>(wptr[ct]);
+    // ---- software pipeline -------------------------------------------------------------------
+    //  * weights (A): NA-slot register queue, loads run NA-1 k-steps ahead of their MFMAs;
+    //  * activations (B): the next k-step's fragments are ds_read while this k-step's MFMAs issue;
+    //  * halo staging: the NEXT 64-channel chunk is fetched global -> registers before this chunk's
+    //    MFMAs and written to the other LDS buffer after them (one barrier per chunk).
+    // No branch inside the K loop: pixel tiles beyond the tile's valid pixels compute on clamped
+    // addresses and are masked in the epilogue only.
+    constexpr int NSTEP = KK * 2;                       // k32 steps per 64-channel chunk
+    // queue depths must divide the per-chunk counts so that slot indices stay compile-time constants
+    constexpr int NA = (PREC == PN_PREC_BF16) ? ((NSTEP % 6 == 0) ? 6 : 2) : ((NSTEP % 3 == 0) ? 3 : 2);
+    constexpr int NITEM = NSTEP * PT;                   // (k-step, pixel tile) items per chunk
+    constexpr int DB = (PREC == PN_PREC_BF16) ? ((NITEM % 3 == 0) ? 3 : 2) : 1;   // B fragments in flight
+    constexpr int MAXST = StageCfg<PREC, KS, STRIDE, PITCH>::MAXST;   // 0: stage without register prefetch
 
-    // staging geometry (thread -> 16-B piece `ch` of halo pixels p0, p0+PPI, ...)
-    const int ch = tid % NCH;
+    const int ch = tid % NCH;                            // thread -> 16-B piece `ch` of halo pixels p0, p0+PPI, ...
     const int p0 = tid / NCH;
     const int npx = HRa * HC;
     const float inv_hc = 1.0f / (float)HC;
-    const char *in_base = (const char *)P.in + ((size_t)P.in_coff * sizeof(T)) + ch * 16;
+    gcptr in_base = (gcptr)P.in + ((size_t)P.in_coff * sizeof(T)) + ch * 16;
+    const int nchunks = P.cin_chunks;
 
-    for (int chunk = 0; chunk < P.cin_chunks; ++chunk) {
-        if (chunk) __syncthreads();
-        // ---- stage the halo tile of this 64-channel chunk ----
-        for (int p = p0; p < npx; p += PPI) {
-            int hy = (int)(((float)p + 0.5f) * inv_hc);
-            int hx = p - hy * HC;
-            int iy = iy0 + hy, ix = ix0 + hx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W) {
-                size_t pix = (size_t)(b * P.H + iy) * P.W + ix;
-                v = *reinterpret_cast<const uint4 *>(in_base + (pix * P.in_cs + (size_t)chunk * 64) * sizeof(T));
-            }
-            int hp = hy * PITCH + hx;
-            int dst;
-            if (PREC == PN_PREC_BF16)
-                dst = hp * PIXB + ((ch ^ (hp & 7)) << 4);
-            else
-                dst = hp * PIXB + ((((ch >> 1) ^ (hp & 7)) << 5) | ((ch & 1) << 4));
-            *reinterpret_cast<uint4 *>(smem + dst) = v;
+    auto halo_src = [&](int p, int chunk, bool &inb) -> gcptr {
+        int hy = (int)(((float)p + 0.5f) * inv_hc);
+        int hx = p - hy * HC;
+        int iy = iy0 + hy, ix = ix0 + hx;
+        inb = p < npx && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
+        iy = min(max(iy, 0), P.H - 1);                  // always a valid address: the load is
+        ix = min(max(ix, 0), P.W - 1);                  // unconditional, padding is a select
+        size_t pix = (size_t)(b * P.H + iy) * P.W + ix;
+        return in_base + (pix * P.in_cs + (size_t)chunk * 64) * sizeof(T);
+    };
+    auto halo_dst = [&](int p) -> int {
+        int hy = (int)(((float)p + 0.5f) * inv_hc);
+        int hx = p - hy * HC;
+        int hp = hy * PITCH + hx;
+        if (PREC == PN_PREC_BF16) return hp * PIXB + ((ch ^ (hp & 7)) << 4);
+        return hp * PIXB + ((((ch >> 1) ^ (hp & 7)) << 5) | ((ch & 1) << 4));
+    };
+    u32x4 st[MAXST > 0 ? MAXST : 1];
+    auto stage_load = [&](int chunk) {                   // all loads issued back to back, no waits:
+#pragma unroll                                           // padding is applied when the registers are stored
+        for (int it = 0; it < MAXST; ++it) {
+            bool inb;
+            gcptr src = halo_src(p0 + it * PPI, chunk, inb);
+            st[it] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(src);
         }
-        __syncthreads();
+    };
+    auto stage_store = [&](char *buf) {
+#pragma unroll
+        for (int it = 0; it < MAXST; ++it) {
+            const int p = p0 + it * PPI;
+            bool inb;
+            (void)halo_src(p, 0, inb);
+            if (p < npx) *reinterpret_cast<u32x4 *>(buf + halo_dst(p)) = inb ? st[it] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stage_direct = [&](int chunk, char *buf) {      // large halos (stride 2, f32): plain loop
+        for (int p = p0; p < npx; p += PPI) {
+            bool inb;
+            gcptr src = halo_src(p, chunk, inb);
+            u32x4 v = *reinterpret_cast<const PN_GLOBAL u32x4 *>(src);
+            if (!inb) v = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(buf + halo_dst(p)) = v;
+        }
+    };
 
+    char *buf0 = smem, *buf1 = P.lds_two ? smem + P.lds_buf_bytes : smem;
+    Frag aq[NA][CT];
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
+    for (int d = 0; d < NA - 1; ++d)
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = load_a_frag<PREC>(wptr[ct] + d * FRAGB);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    a_cur[ct] = a_nxt[ct];
+    for (int ct = 0; ct < CT; ++ct) wptr[ct] += (NA - 1) * FRAGB;
+    if (MAXST > 0) { stage_load(0); stage_store(buf0); }
+    else stage_direct(0, buf0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const char *sm = (chunk & 1) ? buf1 : buf0;
+        char *nbuf = (chunk & 1) ? buf0 : buf1;
+        const bool more = chunk + 1 < nchunks;
+        if (MAXST > 0 && more && !(P.dbg & 2)) stage_load(chunk + 1);
+
+        // B-fragment address of item j = (k-step s, pixel tile pt)
+#define PN_BADDR(j) ((baddr[(j) % PT][(((j) / PT) / 2) % KS] ^ ((((j) / PT) % 2) * SUBX)) + ((((j) / PT) / 2) / KS) * PITCH * PIXB)
+        Frag bq[DB];
+        if (DB > 1) {
+#pragma unroll
+            for (int j = 0; j < DB - 1; ++j) bq[j] = read_b_frag<PREC>(sm, PN_BADDR(j));
+            __builtin_amdgcn_sched_barrier(0);          // keep the primed reads out of the pinned sequence below
+        }
+#pragma unroll
+        for (int j = 0; j < NITEM; ++j) {
+            const int s = j / PT, pt = j % PT;
+            if (pt == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {        // wpack ends with NA-1 spare fragments
+                    if (!(P.dbg & 1)) aq[(s + NA - 1) % NA][ct] = load_a_frag<PREC>(wptr[ct]);
                     wptr[ct] += FRAGB;
-                    a_nxt[ct] = load_a_frag<PREC>(wptr[ct]);   // wpack has one spare fragment at its end
-                }
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    if ((wp * PT + pt) * 16 < npix) {      // wave-uniform
-                        Frag bf = read_b_frag<PREC>(smem, (baddr[pt][kx] ^ (sub * SUBX)) + ky * PITCH * PIXB);
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) acc[ct][pt] = mma(a_cur[ct], bf, acc[ct][pt]);
-                    }
                 }
             }
+            if (DB > 1) {
+                if (j + DB - 1 < NITEM) bq[(j + DB - 1) % DB] = read_b_frag<PREC>(sm, PN_BADDR(j + DB - 1));
+            } else {
+                bq[0] = read_b_frag<PREC>(sm, PN_BADDR(j));
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[ct][pt] = mma(aq[s % NA][ct], bq[DB > 1 ? j % DB : 0], acc[ct][pt]);
+            if (DB > 1) {
+                // pin the issue order (the scheduler otherwise sinks every prefetch down to its use)
+                if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);                 // weight loads
+                if (j + DB - 1 < NITEM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);                              // CT MFMAs
+            }
+        }
+#undef PN_BADDR
+        if (more) {
+            if (!P.lds_two) __syncthreads();             // single LDS image: wait for every wave's reads
+            if (MAXST > 0) { if (!(P.dbg & 2)) stage_store(nbuf); }
+            else stage_direct(chunk + 1, nbuf);
+            __syncthreads();
         }
     }
 
-    // ---- epilogue ----
+    // ---- epilogue ------------------------------------------------------------------------------
+    // The MFMA C layout gives each lane 4 channels of one pixel: stored directly that is an 8-B
+    // write per lane into 16 different 128-B lines per instruction (measured: 40 % of the forward).
+    // Instead the block transposes its (acc + bias) tile through LDS ([pixel slot][cout] f32, rows
+    // padded by 16 B against bank conflicts) and every thread then handles 8 consecutive channels of
+    // one pixel: one 16-B residual load, activation, one 16-B (bf16) / 32-B (f32) store -- whole
+    // lines per pixel.  The NCHW f32 outputs of the last layers are written pixel-major from the
+    // same tile.
+    constexpr int BC = WC * CT * 16;
+    constexpr int ROWB = BC * 4 + 16;
+    constexpr int G = BC / 8;                        // 8-channel groups per pixel (power of two)
     const int act = P.act;
+    if (P.dbg & 4) return;
+    __syncthreads();                                 // every wave is done with the halo image
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int co0 = (ctile0 + ct) * 16 + 4 * q;
-        if (co0 >= P.cout) continue;
-        const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(P.bias + co0);
-        const bool full = (co0 + 3) < P.cout;
+        const int col = (wc * CT + ct) * 16 + 4 * q;
+        const f32x4 bias4 = *reinterpret_cast<const PN_GLOBAL f32x4 *>((const PN_GLOBAL float *)P.bias + cb * BC + col);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            int slot = (wp * PT + pt) * 16 + c;
-            if (slot >= npix) continue;
-            int ry = (int)(((float)slot + 0.5f) * inv_wc);
-            int rx = ox0 + (slot - ry * Wc);
-            size_t opix = (size_t)(b * P.Ho + oy0 + ry) * Wo + rx;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[ct][pt][r] + bias4[r];
+            const int slot = (wp * PT + pt) * 16 + c;
+            *reinterpret_cast<f32x4 *>(smem + slot * ROWB + col * 4) = acc[ct][pt] + bias4;
+        }
+    }
+    __syncthreads();
+    if (P.out) {
+        for (int i = tid; i < npix * G; i += 256) {
+            const int slot = i / G, cg = i % G;
+            const int co = cb * BC + cg * 8;
+            if (co >= P.cout) continue;
+            const int ry = (int)(((float)slot + 0.5f) * inv_wc);
+            const int rx = ox0 + (slot - ry * Wc);
+            const size_t opix = (size_t)(b * P.Ho + oy0 + ry) * Wo + rx;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + slot * ROWB + cg * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + slot * ROWB + cg * 32 + 16);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bool full = co + 7 < P.cout;
             if (P.res) {
-                const T *rp = (const T *)P.res + opix * P.res_cs + P.res_coff + co0;
+                const PN_GLOBAL T *rp = (const PN_GLOBAL T *)P.res + opix * P.res_cs + P.res_coff + co;
+                if (full) {
+                    T rv[8];
+                    if (sizeof(T) == 2) {
+                        *reinterpret_cast<u32x4 *>(rv) = *reinterpret_cast<const PN_GLOBAL u32x4 *>(rp);
+                    } else {
+                        reinterpret_cast<u32x4 *>(rv)[0] = reinterpret_cast<const PN_GLOBAL u32x4 *>(rp)[0];
+                        reinterpret_cast<u32x4 *>(rv)[1] = reinterpret_cast<const PN_GLOBAL u32x4 *>(rp)[1];
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (full || co0 + r < P.cout) v[r] += (float)rp[r];
+                    for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
+                } else {
+                    for (int k = 0; k < 8; ++k)
+                        if (co + k < P.cout) v[k] += (float)rp[k];
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = pn_activate(v[r], act, co0 + r, P.yolo_naf);
-            if (P.out) {
-                T *op = (T *)P.out + opix * P.out_cs + P.out_coff + co0;
-                if (full) store4(op, v);
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (co0 + r < P.cout) op[r] = (T)v[r];
-            }
-            if (P.out_nchw) {
-                size_t hw = (size_t)P.Ho * Wo;
-                float *np = P.out_nchw + ((size_t)b * P.cout + co0) * hw + (size_t)(oy0 + ry) * Wo + rx;
+            for (int k = 0; k < 8; ++k) v[k] = pn_activate(v[k], act, co + k, P.yolo_naf);
+            PN_GLOBAL T *op = (PN_GLOBAL T *)P.out + opix * P.out_cs + P.out_coff + co;
+            if (P.dbg & 8) { if (v[0] == 1234.5f) op[0] = (T)v[1]; continue; }   // timing ablation: no stores
+            if (full) {
+                T ov[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (full || co0 + r < P.cout) np[r * hw] = v[r];
+                for (int k = 0; k < 8; ++k) ov[k] = (T)v[k];
+                if (sizeof(T) == 2) {
+                    *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
+                } else {
+                    reinterpret_cast<PN_GLOBAL u32x4 *>(op)[0] = reinterpret_cast<u32x4 *>(ov)[0];
+                    reinterpret_cast<PN_GLOBAL u32x4 *>(op)[1] = reinterpret_cast<u32x4 *>(ov)[1];
+                }
+            } else {
+                for (int k = 0; k < 8; ++k)
+                    if (co + k < P.cout) op[k] = (T)v[k];
             }
+        }
+    }
+    if (P.out_nchw) {
+        const int ncol = min(BC, P.cout - cb * BC);
+        const size_t hw = (size_t)P.Ho * Wo;
+        for (int i = tid; i < ncol * npix; i += 256) {
+            const int col = i / npix, slot = i - col * npix;
+            const int co = cb * BC + col;
+            const int ry = (int)(((float)slot + 0.5f) * inv_wc);
+            const int rx = ox0 + (slot - ry * Wc);
+            float v = *reinterpret_cast<const float *>(smem + slot * ROWB + col * 4);
+            v = pn_activate(v, act, co, P.yolo_naf);
+            ((PN_GLOBAL float *)P.out_nchw)[((size_t)b * P.cout + co) * hw + (size_t)(oy0 + ry) * Wo + rx] = v;
         }
     }
 }

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -191,7 +192,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const int KK = ks * ks;
     const int ksteps = cs.cin_chunks * KK * 2;
     const size_t fragb = n->prec == PN_PREC_BF16 ? 1024 : 2048;
-    const size_t bytes = (size_t)ctiles * ksteps * fragb + fragb;   // + one spare fragment (prefetch overrun)
+    const size_t bytes = (size_t)ctiles * ksteps * fragb + 5 * fragb;   // + spare fragments (the weight queue prefetches up to 5 k-steps ahead)
     std::vector<unsigned char> host(bytes, 0);
     uint16_t *h16 = reinterpret_cast<uint16_t *>(host.data());
     float *h32 = reinterpret_cast<float *>(host.data());
@@ -228,6 +229,12 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const int segs = (Wo + BP - 1) / BP;
     cs.Wt = (Wo + segs - 1) / segs;
     cs.R = std::max(1, std::min(Ho, BP / cs.Wt));
+    {   // the register-prefetched staging path holds at most this many halo pixels
+        const int maxpx = pn_conv_stage_maxpx(n->prec, ks, cs.stride, pick_pitch((cs.Wt - 1) * cs.stride + ks));
+        while (maxpx > 0 && cs.R > 1 && ((cs.R - 1) * cs.stride + ks) * ((cs.Wt - 1) * cs.stride + ks) > maxpx) --cs.R;
+        if (maxpx > 0 && ((cs.R - 1) * cs.stride + ks) * ((cs.Wt - 1) * cs.stride + ks) > maxpx)
+            return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo tile exceeds the staging capacity", cs.w.c_str());
+    }
     cs.pitch = pick_pitch((cs.Wt - 1) * cs.stride + ks);
     if (cs.pitch < 0) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo width %d has no pitch class", cs.w.c_str(), (cs.Wt - 1) * cs.stride + ks);
     cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
@@ -445,6 +452,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         const int BC = pn_cfg_couts(c0.cfg);
         st.host_probs.clear();
         int max_blocks = 0;
+        bool two_bufs = false;
         for (int id : st.conv_ids) {
             const ConvSpec &cs = n->convs[id];
             const Buf &ib = n->bufs[cs.in_buf];
@@ -473,6 +481,10 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.cout_blocks = (cs.cout + BC - 1) / BC;
             P.nblocks = B * P.tiles_per_img * P.cout_blocks;
             P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
+            P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
+            P.dbg = getenv("POPNET_DBG") ? atoi(getenv("POPNET_DBG")) : 0;
+            P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
+            if (P.lds_two) two_bufs = true;
             max_blocks = std::max(max_blocks, P.nblocks);
             st.host_probs.push_back(P);
         }
@@ -480,7 +492,11 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.ks = c0.ks; st.launch.stride = c0.stride; st.launch.pitch = c0.pitch; st.launch.cfg = c0.cfg;
         st.launch.nprob = (int)st.host_probs.size();
         st.launch.max_blocks = max_blocks;
-        st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R);
+        st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R) * (two_bufs ? 2 : 1);
+        {   // the epilogue transposes the f32 output tile through the same LDS allocation
+            const size_t bp = c0.cfg == PN_CFG_C128 ? 112 : 128;
+            st.launch.lds_bytes = std::max(st.launch.lds_bytes, bp * ((size_t)BC * 4 + 16));
+        }
         st.launch.probs_dev = st.dev_probs;
         PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),
                                             hipMemcpyHostToDevice, stream));

@@ -61,6 +61,9 @@ struct ConvProblem {
     int cout_blocks;       // ceil(cout / (WC*CT*16))
     int nblocks;           // B * tiles_per_img * cout_blocks
     int ksteps;            // cin_chunks * KS*KS * 2   (k32 steps per cout tile in wpack)
+    int lds_buf_bytes;     // bytes of one LDS halo image
+    int lds_two;           // 1: a second image follows (double-buffered chunks), 0: single image
+    int dbg;               // timing ablations only ($POPNET_DBG): 1 = reuse first weight fragments, 2 = stage chunk 0 only, 4 = skip epilogue stores
 };
 
 // Tile configuration ids (see conv_mfma.hip).
@@ -85,6 +88,7 @@ struct ConvLaunch {
 };
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
+int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch);   // 0 = no limit (direct staging)
 
 // stem: 7x7 stride-2 pad-3, Cin = 1, fused folded-BN bias + ReLU.  x NCHW f32 [B,1,H,W] ->
 // NHWC T [B,Ho,Wo,64].  w [49][64] f32 (tap-major), bias [64].
