@@ -7,11 +7,14 @@ int pn_cfg_couts(int cfg) {
     switch (cfg) {
         case PN_CFG_C128: return 128;
         case PN_CFG_C64: return 64;
+        case PN_CFG_C64W: return 64;
         case PN_CFG_C32: return 32;
         default: return 16;
     }
 }
 
+
+int pn_cfg_pixels(int cfg) { return cfg == PN_CFG_C128 ? 112 : (cfg == PN_CFG_C64W ? 224 : 128); }
 
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R) {
     size_t pixb = prec == PN_PREC_BF16 ? 128 : 256;
@@ -36,7 +39,8 @@ int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
 
 // host mirror of StageCfg (conv_mfma_kernel.h): largest halo tile (pixels) the register-prefetched
 // staging path of this instantiation can hold; 0 = that instantiation stages with the plain loop.
-int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch) {
+int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg) {
+    if (cfg == PN_CFG_C64W) return 0;
     const int maxpx = stride != 1 ? 0 : (ks == 1 ? 128 : (pitch <= 32 ? 192 : (pitch <= 64 ? 288 : 360)));
     const int nch = prec == PN_PREC_BF16 ? 8 : 16;
     const int raw = (maxpx * nch + 255) / 256;

@@ -58,6 +58,7 @@ template <> struct TileCfg<PN_CFG_C128> { static constexpr int WC = 4, WP = 1, C
 template <> struct TileCfg<PN_CFG_C64>  { static constexpr int WC = 2, WP = 2, CT = 2, PT = 4; };
 template <> struct TileCfg<PN_CFG_C32>  { static constexpr int WC = 1, WP = 4, CT = 2, PT = 2; };
 template <> struct TileCfg<PN_CFG_C16>  { static constexpr int WC = 1, WP = 4, CT = 1, PT = 2; };
+template <> struct TileCfg<PN_CFG_C64W> { static constexpr int WC = 2, WP = 2, CT = 2, PT = 7; };
 
 __device__ __forceinline__ float pn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -137,10 +138,10 @@ __device__ __forceinline__ void store4(PN_GLOBAL float *p, const float v[4]) {
 constexpr int pn_stage_maxpx_c(int ks, int stride, int pitch) {
     return stride != 1 ? 0 : (ks == 1 ? 128 : (pitch <= 32 ? 192 : (pitch <= 64 ? 288 : 360)));
 }
-template <int PREC, int KS, int STRIDE, int PITCH> struct StageCfg {
+template <int PREC, int KS, int STRIDE, int PITCH, int CFG> struct StageCfg {
     static constexpr int NCH = Elem<PREC>::PIXB / 16;
     static constexpr int RAW = (pn_stage_maxpx_c(KS, STRIDE, PITCH) * NCH + 255) / 256;
-    static constexpr int MAXST = RAW <= 12 ? RAW : 0;
+    static constexpr int MAXST = (RAW <= 12 && CFG != PN_CFG_C64W) ? RAW : 0;
 };
 
 template <int PREC, int KS, int STRIDE, int PITCH, int CFG>
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     constexpr int NA = (PREC == PN_PREC_BF16) ? ((NSTEP % 6 == 0) ? 6 : 2) : ((NSTEP % 3 == 0) ? 3 : 2);
     constexpr int NITEM = NSTEP * PT;                   // (k-step, pixel tile) items per chunk
     constexpr int DB = (PREC == PN_PREC_BF16) ? ((NITEM % 3 == 0) ? 3 : 2) : 1;   // B fragments in flight
-    constexpr int MAXST = StageCfg<PREC, KS, STRIDE, PITCH>::MAXST;   // 0: stage without register prefetch
+    constexpr int MAXST = StageCfg<PREC, KS, STRIDE, PITCH, CFG>::MAXST;   // 0: stage without register prefetch
 
     const int ch = tid % NCH;                            // thread -> 16-B piece `ch` of halo pixels p0, p0+PPI, ...
     const int p0 = tid / NCH;
@@ -275,13 +276,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
             if (p < npx) *reinterpret_cast<u32x4 *>(buf + halo_dst(p)) = inb ? st[it] : u32x4{0u, 0u, 0u, 0u};
         }
     };
-    auto stage_direct = [&](int chunk, char *buf) {      // large halos (stride 2, f32): plain loop
-        for (int p = p0; p < npx; p += PPI) {
-            bool inb;
-            gcptr src = halo_src(p, chunk, inb);
-            u32x4 v = *reinterpret_cast<const PN_GLOBAL u32x4 *>(src);
-            if (!inb) v = u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4 *>(buf + halo_dst(p)) = v;
+    auto stage_direct = [&](int chunk, char *buf) {      // large halos: batches of 4 loads, then 4 stores
+        for (int pb = p0; pb < npx; pb += 4 * PPI) {
+            u32x4 v[4];
+            bool inb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(halo_src(pb + k * PPI, chunk, inb[k]));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (pb + k * PPI < npx) *reinterpret_cast<u32x4 *>(buf + halo_dst(pb + k * PPI)) = inb[k] ? v[k] : u32x4{0u, 0u, 0u, 0u};
         }
     };
 

@@ -224,13 +224,15 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     // geometry
     const Buf &ib = n->bufs[cs.in_buf];
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
-    const int BP = cs.cfg == PN_CFG_C128 ? 112 : 128;
+    if (cs.cfg == PN_CFG_C64 && ks == 3 && cs.stride == 1 && Wo >= 48 && (long)Ho * Wo >= 2048) cs.cfg = PN_CFG_C64W;   // wide maps: 224-pixel tiles
+    const int BP = pn_cfg_pixels(cs.cfg);
     // a block owns R full rows when they fit its pixel tile, else one row cut into equal segments
-    const int segs = (Wo + BP - 1) / BP;
+    const int wt_cap = std::min(BP, (120 - ks) / cs.stride + 1);     // widest segment the largest pitch class holds
+    const int segs = (Wo + wt_cap - 1) / wt_cap;
     cs.Wt = (Wo + segs - 1) / segs;
     cs.R = std::max(1, std::min(Ho, BP / cs.Wt));
     {   // the register-prefetched staging path holds at most this many halo pixels
-        const int maxpx = pn_conv_stage_maxpx(n->prec, ks, cs.stride, pick_pitch((cs.Wt - 1) * cs.stride + ks));
+        const int maxpx = pn_conv_stage_maxpx(n->prec, ks, cs.stride, pick_pitch((cs.Wt - 1) * cs.stride + ks), cs.cfg);
         while (maxpx > 0 && cs.R > 1 && ((cs.R - 1) * cs.stride + ks) * ((cs.Wt - 1) * cs.stride + ks) > maxpx) --cs.R;
         if (maxpx > 0 && ((cs.R - 1) * cs.stride + ks) * ((cs.Wt - 1) * cs.stride + ks) > maxpx)
             return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo tile exceeds the staging capacity", cs.w.c_str());
@@ -494,7 +496,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.max_blocks = max_blocks;
         st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R) * (two_bufs ? 2 : 1);
         {   // the epilogue transposes the f32 output tile through the same LDS allocation
-            const size_t bp = c0.cfg == PN_CFG_C128 ? 112 : 128;
+            const size_t bp = pn_cfg_pixels(c0.cfg);
             st.launch.lds_bytes = std::max(st.launch.lds_bytes, bp * ((size_t)BC * 4 + 16));
         }
         st.launch.probs_dev = st.dev_probs;

@@ -71,9 +71,11 @@ enum pn_conv_cfg {
     PN_CFG_C128 = 0,  // 4x1 waves, 2 cout tiles x 7 pixel tiles per wave: 128 couts x 112 px
     PN_CFG_C64 = 1,   // 2x2 waves, 2 cout tiles x 4 pixel tiles per wave:  64 couts x 128 px
     PN_CFG_C32 = 2,   // 1x4 waves, 2 cout tiles x 2 pixel tiles per wave:  32 couts x 128 px
-    PN_CFG_C16 = 3    // 1x4 waves, 1 cout tile  x 2 pixel tiles per wave:  16 couts x 128 px
+    PN_CFG_C16 = 3,   // 1x4 waves, 1 cout tile  x 2 pixel tiles per wave:  16 couts x 128 px
+    PN_CFG_C64W = 4   // 2x2 waves, 2 cout tiles x 7 pixel tiles per wave:  64 couts x 224 px (wide maps)
 };
 int pn_cfg_couts(int cfg);
+int pn_cfg_pixels(int cfg);
 
 struct ConvLaunch {
     int prec;      // pn_precision
@@ -88,7 +90,7 @@ struct ConvLaunch {
 };
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
-int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch);   // 0 = no limit (direct staging)
+int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 0 = no limit (direct staging)
 
 // stem: 7x7 stride-2 pad-3, Cin = 1, fused folded-BN bias + ReLU.  x NCHW f32 [B,1,H,W] ->
 // NHWC T [B,Ho,Wo,64].  w [49][64] f32 (tap-major), bias [64].
