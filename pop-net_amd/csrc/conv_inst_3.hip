@@ -1,5 +1,5 @@
 // MFMA convolution instantiations, share 3 of 4 (see conv_mfma.hip).
-#include "conv_mfma_persist.h"
+#include "conv_mfma_kernel.h"
 
 int pn_launch_conv_part3(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
     PN_CASES_ALLCFG(3, 1, 16)

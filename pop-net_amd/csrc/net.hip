@@ -10,7 +10,6 @@
 // the stem and the three stage-1 heads write straight into one 192-channel NHWC buffer laid out
 // [feat 0..127 | paf 128..155 | heat 156..171 | z 172..186 | 0-pad], and the stage-2 weights'
 // input channels are permuted to that order when they are packed.
-#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -85,9 +84,6 @@ struct pn_net {
     std::vector<Buf> bufs;
     std::vector<ConvSpec> convs;
     std::vector<Step> steps;
-    int *counters = nullptr;          // one tile counter per conv launch (persistent kernels)
-    int ncounters = 0;
-    int persist = 1;
     std::vector<void *> dev_allocs;
     float *nchw_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_B = -1;
@@ -457,10 +453,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         const ConvSpec &c0 = n->convs[st.conv_ids[0]];
         const int BC = pn_cfg_couts(c0.cfg);
         st.host_probs.clear();
-        std::stable_sort(st.conv_ids.begin(), st.conv_ids.end(), [&](int a, int b) {
-            return n->convs[a].cin_chunks * n->convs[a].ks > n->convs[b].cin_chunks * n->convs[b].ks; });   // longest tiles first
         int max_blocks = 0;
-        int total_tiles = 0;
         bool two_bufs = false;
         for (int id : st.conv_ids) {
             const ConvSpec &cs = n->convs[id];
@@ -492,11 +485,9 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
             P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
             P.dbg = getenv("POPNET_DBG") ? atoi(getenv("POPNET_DBG")) : 0;
-            P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes + 64 <= 160 * 1024) ? 1 : 0;   // + the persistent kernel's hand-over word
+            P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
             if (P.lds_two) two_bufs = true;
             max_blocks = std::max(max_blocks, P.nblocks);
-            P.tile_base = total_tiles;
-            total_tiles += P.nblocks;
             st.host_probs.push_back(P);
         }
         st.launch.prec = n->prec;
@@ -509,9 +500,6 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             st.launch.lds_bytes = std::max(st.launch.lds_bytes, bp * ((size_t)BC * 4 + 16));
         }
         st.launch.probs_dev = st.dev_probs;
-        st.launch.persist = n->persist;
-        st.launch.total_tiles = total_tiles;
-        st.launch.counter = n->counters + (&st - &n->steps[0]);
         PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),
                                             hipMemcpyHostToDevice, stream));
     }
@@ -528,7 +516,6 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
     for (int i = 0; i < 4; ++i) dirty |= n->nchw_ptr[i] != n->last_nchw[i];
     if (dirty)
         if (int rc = refresh_problems(n, B, stream)) return rc;
-    if (n->persist) PN_HIP_CHECK(ctx, hipMemsetAsync(n->counters, 0, (size_t)n->ncounters * sizeof(int), stream));
     for (auto &st : n->steps) {
         int rc = PN_OK;
         pn_net::ProfRec *pr = nullptr;
@@ -618,10 +605,6 @@ int pn_net_finalize(pn_net *n, int precision, int max_batch, int in_h, int in_w)
     for (auto &st : n->steps)
         if (st.type == Step::CONV)
             if (int r = dev_alloc(n, (void **)&st.dev_probs, st.conv_ids.size() * sizeof(ConvProblem), true)) return r;
-    n->ncounters = (int)n->steps.size() + 4;
-    n->ncounters = (n->ncounters + 3) / 4 * 4;      // memset blocks of a multiple of 16 bytes
-    if (int r = dev_alloc(n, (void **)&n->counters, (size_t)n->ncounters * sizeof(int), true)) return r;
-    n->persist = getenv("POPNET_PERSIST") ? atoi(getenv("POPNET_PERSIST")) : 1;
     n->tensors.clear();
     n->finalized = true;
     return PN_OK;

@@ -63,7 +63,6 @@ struct ConvProblem {
     int ksteps;            // cin_chunks * KS*KS * 2   (k32 steps per cout tile in wpack)
     int lds_buf_bytes;     // bytes of one LDS halo image
     int lds_two;           // 1: a second image follows (double-buffered chunks), 0: single image
-    int tile_base;         // persistent launches: global id of this problem's first tile (problems listed longest first)
     int dbg;               // timing ablations only ($POPNET_DBG): 1 = reuse first weight fragments, 2 = stage chunk 0 only, 4 = skip epilogue stores
 };
 
@@ -88,9 +87,6 @@ struct ConvLaunch {
     int max_blocks;          // max nblocks over the group
     size_t lds_bytes;
     const ConvProblem *probs_dev;
-    int persist;             // 1: persistent tile-queue kernel (conv_mfma_persist.h), 0: one block per tile
-    int total_tiles;         // sum of nblocks over the group
-    int *counter;            // device tile counter of this launch (zeroed at the start of every forward)
 };
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);

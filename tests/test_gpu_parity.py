@@ -336,3 +336,48 @@ def test_engine_bf16_full_batch_runs_and_parse_is_self_consistent(gpu):
         if assoc.size:
             assert np.array_equal(assoc[:, :15], rec["assoc"][:, :15])
             assert np.array_equal(recs[b]["joints_3d"][:assoc.shape[0]], np.array(rec["humans_3d"]))
+
+
+def test_hipgraph_replay_equals_eager(gpu):
+    """bench.py replays one captured hipGraph per step: the replayed step must reproduce the eager
+    maps and records exactly, for inputs different from the ones seen at capture time."""
+    from popnet_amd.pipeline import PoseEngine
+    eng = PoseEngine(precision="bf16", device=gpu, max_batch=32)
+    item = _lib.POSE_FRAME_DTYPE.itemsize
+    d1 = torch.from_numpy(synth.synth_depth(32, seed=1)).to(gpu)
+    d2 = torch.from_numpy(synth.synth_depth(32, seed=2)).to(gpu)
+    static_in = d1.clone()
+    out = torch.zeros((32, item), device=gpu, dtype=torch.uint8)
+
+    def body():
+        eng.predict(static_in, out)
+
+    def snapshot():
+        torch.cuda.synchronize()
+        r = out.cpu().numpy().view(_lib.POSE_FRAME_DTYPE).reshape(-1)
+        return eng.heat.clone(), eng.paf.clone(), eng.z.clone(), [(int(f["n_peaks"]), int(f["n_persons"]), f["person_joint"][:int(f["n_persons"])].tobytes()) for f in r]
+
+    for _ in range(2):
+        body()
+    eager = {}
+    for name, d in (("d1", d1), ("d2", d2)):
+        static_in.copy_(d)
+        body()
+        eager[name] = snapshot()
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        body()
+    for _ in range(2):
+        for name, d in (("d2", d2), ("d1", d1)):
+            static_in.copy_(d)
+            out.zero_(); eng.heat.zero_(); eng.paf.zero_(); eng.z.zero_()
+            g.replay()
+            h, p, z, recs = snapshot()
+            assert torch.equal(h, eager[name][0]) and torch.equal(p, eager[name][1]) and torch.equal(z, eager[name][2])
+            assert recs == eager[name][3]
