@@ -144,6 +144,13 @@ template <int PREC, int KS, int STRIDE, int PITCH, int CFG> struct StageCfg {
     static constexpr int MAXST = (RAW <= 12 && CFG != PN_CFG_C64W) ? RAW : 0;
 };
 
+// Weight fragments are addressed as (wave-uniform 64-bit base in SGPRs) + (32-bit lane offset): the
+// compiler then emits the saddr form of global_load and bumps the base with scalar adds -- no vector
+// ALU work per k-step.
+template <int PREC> __device__ __forceinline__ typename Elem<PREC>::Frag load_a_frag2(gcptr base, unsigned voff) {
+    return load_a_frag<PREC>(base + voff);
+}
+
 template <int PREC, int KS, int STRIDE, int PITCH, int CFG>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__restrict__ probs) {
     typedef Elem<PREC> E;
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int NCH = PIXB / 16;      // 16-B pieces per halo pixel
     constexpr int PPI = 256 / NCH;      // halo pixels staged per block pass
+    constexpr int ES = (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const ConvProblem &P = probs[blockIdx.y];
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
     const float inv_wc = 1.0f / (float)Wc;
 
-    // ---- per-lane LDS addresses of tap (ky=0,kx) for each pixel tile, first 32-channel half ----
+    // ---- per-lane LDS addresses of tap (ky=0,kx) for each pixel tile, current 32-channel half ----
     int baddr[PT][KS];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -201,10 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
             int hp = hp0 + kx;
-            if (PREC == PN_PREC_BF16)
-                baddr[pt][kx] = hp * PIXB + ((q ^ (hp & 7)) << 4);
-            else
-                baddr[pt][kx] = hp * PIXB + ((q ^ (hp & 7)) << 5);
+            baddr[pt][kx] = hp * PIXB + ((q ^ (hp & 7)) << (PREC == PN_PREC_BF16 ? 4 : 5));
         }
     }
 
@@ -214,77 +219,90 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int ctile0 = (cb * WC + wc) * CT;
-    gcptr wptr[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-        wptr[ct] = (gcptr)P.wpack + (size_t)(ctile0 + ct) * P.ksteps * FRAGB + lane * 16;
-
     // ---- software pipeline -------------------------------------------------------------------
+    //  * k order inside a 64-channel chunk: (32-channel half, tap): the swizzled LDS address of the
+    //    second half is the first half's XOR SUBX, so the XOR is applied once per half (not per read);
     //  * weights (A): NA-slot register queue, loads run NA-1 k-steps ahead of their MFMAs;
-    //  * activations (B): the next k-step's fragments are ds_read while this k-step's MFMAs issue;
-    //  * halo staging: the NEXT 64-channel chunk is fetched global -> registers before this chunk's
-    //    MFMAs and written to the other LDS buffer after them (one barrier per chunk).
+    //  * activations (B): DB fragments in flight, read between the MFMAs of earlier pixel tiles;
+    //  * halo staging: the NEXT chunk is fetched global -> registers before this chunk's MFMAs and
+    //    written to the other LDS image after them (one barrier per chunk).
     // No branch inside the K loop: pixel tiles beyond the tile's valid pixels compute on clamped
     // addresses and are masked in the epilogue only.
     constexpr int NSTEP = KK * 2;                       // k32 steps per 64-channel chunk
-    // queue depths must divide the per-chunk counts so that slot indices stay compile-time constants
     constexpr int NA = (PREC == PN_PREC_BF16) ? ((NSTEP % 6 == 0) ? 6 : 2) : ((NSTEP % 3 == 0) ? 3 : 2);
     constexpr int NITEM = NSTEP * PT;                   // (k-step, pixel tile) items per chunk
     constexpr int DB = (PREC == PN_PREC_BF16) ? ((NITEM % 3 == 0) ? 3 : 2) : 1;   // B fragments in flight
     constexpr int MAXST = StageCfg<PREC, KS, STRIDE, PITCH, CFG>::MAXST;   // 0: stage without register prefetch
-
-    const int ch = tid % NCH;                            // thread -> 16-B piece `ch` of halo pixels p0, p0+PPI, ...
-    const int p0 = tid / NCH;
-    const int npx = HRa * HC;
-    const float inv_hc = 1.0f / (float)HC;
-    gcptr in_base = (gcptr)P.in + ((size_t)P.in_coff * sizeof(T)) + ch * 16;
     const int nchunks = P.cin_chunks;
 
-    auto halo_src = [&](int p, int chunk, bool &inb) -> gcptr {
-        int hy = (int)(((float)p + 0.5f) * inv_hc);
-        int hx = p - hy * HC;
-        int iy = iy0 + hy, ix = ix0 + hx;
-        inb = p < npx && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
-        iy = min(max(iy, 0), P.H - 1);                  // always a valid address: the load is
-        ix = min(max(ix, 0), P.W - 1);                  // unconditional, padding is a select
-        size_t pix = (size_t)(b * P.H + iy) * P.W + ix;
-        return in_base + (pix * P.in_cs + (size_t)chunk * 64) * sizeof(T);
+    // weight stream: scalar base per cout tile + lane offset
+    const int ctile0 = (cb * WC + wc) * CT;
+    gcptr wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wbase[ct] = (gcptr)P.wpack + (size_t)(ctile0 + ct) * P.ksteps * FRAGB;
+    const unsigned wlane = (unsigned)lane * 16u;
+
+    // halo staging: thread -> 16-B piece `ch` of halo pixels p0, p0+PPI, ...; coordinates advance
+    // incrementally (no division per piece), global offsets are 32-bit from a scalar image base.
+    const int ch = tid % NCH;
+    const int p0 = tid / NCH;
+    const int npx = HRa * HC;
+    const int hy_first = (int)(((float)p0 + 0.5f) / (float)HC);
+    const int hx_first = p0 - hy_first * HC;
+    const int wrap1 = PPI / HC, wrap_rem = PPI - wrap1 * HC;         // one staging step = wrap1 rows + wrap_rem columns
+    gcptr img = (gcptr)P.in + ((size_t)b * P.H * P.W * P.in_cs + P.in_coff) * ES + ch * 16;
+    const int row_b = P.W * P.in_cs * ES, col_b = P.in_cs * ES;
+    auto piece = [&](int hy, int hx, int &soff, int &dst, bool &inb) {
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        inb = (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
+        const int iyc = min(max(iy, 0), P.H - 1), ixc = min(max(ix, 0), P.W - 1);   // always a valid address
+        soff = iyc * row_b + ixc * col_b;
+        const int hp = hy * PITCH + hx;
+        dst = hp * PIXB + (PREC == PN_PREC_BF16 ? ((ch ^ (hp & 7)) << 4) : ((((ch >> 1) ^ (hp & 7)) << 5) | ((ch & 1) << 4)));
     };
-    auto halo_dst = [&](int p) -> int {
-        int hy = (int)(((float)p + 0.5f) * inv_hc);
-        int hx = p - hy * HC;
-        int hp = hy * PITCH + hx;
-        if (PREC == PN_PREC_BF16) return hp * PIXB + ((ch ^ (hp & 7)) << 4);
-        return hp * PIXB + ((((ch >> 1) ^ (hp & 7)) << 5) | ((ch & 1) << 4));
+    auto advance = [&](int &hy, int &hx) {
+        hx += wrap_rem;
+        hy += wrap1;
+        if (hx >= HC) { hx -= HC; ++hy; }
     };
     u32x4 st[MAXST > 0 ? MAXST : 1];
-    auto stage_load = [&](int chunk) {                   // all loads issued back to back, no waits:
-#pragma unroll                                           // padding is applied when the registers are stored
-        for (int it = 0; it < MAXST; ++it) {
-            bool inb;
-            gcptr src = halo_src(p0 + it * PPI, chunk, inb);
-            st[it] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(src);
-        }
-    };
-    auto stage_store = [&](char *buf) {
+    auto stage_load = [&](int chunk) {                   // all loads issued back to back, no waits
+        int hy = hy_first, hx = hx_first;
+        gcptr src = img + (size_t)chunk * 64 * ES;
 #pragma unroll
         for (int it = 0; it < MAXST; ++it) {
-            const int p = p0 + it * PPI;
-            bool inb;
-            (void)halo_src(p, 0, inb);
-            if (p < npx) *reinterpret_cast<u32x4 *>(buf + halo_dst(p)) = inb ? st[it] : u32x4{0u, 0u, 0u, 0u};
+            int soff, dst; bool inb;
+            piece(hy, hx, soff, dst, inb);
+            st[it] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(src + (unsigned)soff);
+            advance(hy, hx);
+        }
+    };
+    auto stage_store = [&](char *buf) {                  // zero padding is applied here, not at load time
+        int hy = hy_first, hx = hx_first;
+#pragma unroll
+        for (int it = 0; it < MAXST; ++it) {
+            int soff, dst; bool inb;
+            piece(hy, hx, soff, dst, inb);
+            if (p0 + it * PPI < npx) *reinterpret_cast<u32x4 *>(buf + dst) = inb ? st[it] : u32x4{0u, 0u, 0u, 0u};
+            advance(hy, hx);
         }
     };
     auto stage_direct = [&](int chunk, char *buf) {      // large halos: batches of 4 loads, then 4 stores
+        int hy = hy_first, hx = hx_first;
+        gcptr src = img + (size_t)chunk * 64 * ES;
         for (int pb = p0; pb < npx; pb += 4 * PPI) {
             u32x4 v[4];
-            bool inb[4];
+            int dst[4]; bool inb[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(halo_src(pb + k * PPI, chunk, inb[k]));
+            for (int k = 0; k < 4; ++k) {
+                int soff;
+                piece(hy, hx, soff, dst[k], inb[k]);
+                v[k] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(src + (unsigned)soff);
+                advance(hy, hx);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (pb + k * PPI < npx) *reinterpret_cast<u32x4 *>(buf + halo_dst(pb + k * PPI)) = inb[k] ? v[k] : u32x4{0u, 0u, 0u, 0u};
+                if (pb + k * PPI < npx) *reinterpret_cast<u32x4 *>(buf + dst[k]) = inb[k] ? v[k] : u32x4{0u, 0u, 0u, 0u};
         }
     };
 
@@ -293,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
 #pragma unroll
     for (int d = 0; d < NA - 1; ++d)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = load_a_frag<PREC>(wptr[ct] + d * FRAGB);
+        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = load_a_frag2<PREC>(wbase[ct] + d * FRAGB, wlane);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) wptr[ct] += (NA - 1) * FRAGB;
+    for (int ct = 0; ct < CT; ++ct) wbase[ct] += (NA - 1) * FRAGB;
     if (MAXST > 0) { stage_load(0); stage_store(buf0); }
     else stage_direct(0, buf0);
     __syncthreads();
@@ -304,44 +322,54 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
         const char *sm = (chunk & 1) ? buf1 : buf0;
         char *nbuf = (chunk & 1) ? buf0 : buf1;
         const bool more = chunk + 1 < nchunks;
-        if (MAXST > 0 && more && !(P.dbg & 2)) stage_load(chunk + 1);
+        if (MAXST > 0 && more) stage_load(chunk + 1);
 
-        // B-fragment address of item j = (k-step s, pixel tile pt)
-#define PN_BADDR(j) ((baddr[(j) % PT][(((j) / PT) / 2) % KS] ^ ((((j) / PT) % 2) * SUBX)) + ((((j) / PT) / 2) / KS) * PITCH * PIXB)
+        // item j = (k-step s = half * KK + tap, pixel tile pt); the half is selected by the XOR state of baddr
+#define PN_BADDR(j) (baddr[(j) % PT][(((j) / PT) % KK) % KS] + ((((j) / PT) % KK) / KS) * PITCH * PIXB)
         Frag bq[DB];
         if (DB > 1) {
 #pragma unroll
             for (int j = 0; j < DB - 1; ++j) bq[j] = read_b_frag<PREC>(sm, PN_BADDR(j));
             __builtin_amdgcn_sched_barrier(0);          // keep the primed reads out of the pinned sequence below
         }
+#define PN_BADDRX(j) ((baddr[(j) % PT][(((j) / PT) % KK) % KS] ^ SUBX) + ((((j) / PT) % KK) / KS) * PITCH * PIXB)
 #pragma unroll
-        for (int j = 0; j < NITEM; ++j) {
-            const int s = j / PT, pt = j % PT;
-            if (pt == 0) {
+        for (int h = 0; h < 2; ++h) {                    // the two 32-channel halves of the chunk
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {        // wpack ends with NA-1 spare fragments
-                    if (!(P.dbg & 1)) aq[(s + NA - 1) % NA][ct] = load_a_frag<PREC>(wptr[ct]);
-                    wptr[ct] += FRAGB;
+            for (int i = 0; i < KK * PT; ++i) {
+                const int j = h * KK * PT + i, s = j / PT, pt = j % PT;
+                if (pt == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {    // wpack ends with NA-1 spare fragments
+                        aq[(s + NA - 1) % NA][ct] = load_a_frag2<PREC>(wbase[ct], wlane);
+                        wbase[ct] += FRAGB;
+                    }
+                }
+                const int jr = (DB > 1) ? j + DB - 1 : j;                // item whose B fragment is read now
+                if (jr < NITEM) {
+                    // the few prefetches that already belong to the other half take the XOR explicitly
+                    if (jr / (KK * PT) != h) bq[jr % DB] = read_b_frag<PREC>(sm, PN_BADDRX(jr));
+                    else bq[jr % DB] = read_b_frag<PREC>(sm, PN_BADDR(jr));
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[ct][pt] = mma(aq[s % NA][ct], bq[j % DB], acc[ct][pt]);
+                if (DB > 1) {
+                    // pin the issue order (the scheduler otherwise sinks every prefetch down to its use)
+                    if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);             // weight loads
+                    if (jr < NITEM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one LDS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);                          // CT MFMAs
                 }
             }
-            if (DB > 1) {
-                if (j + DB - 1 < NITEM) bq[(j + DB - 1) % DB] = read_b_frag<PREC>(sm, PN_BADDR(j + DB - 1));
-            } else {
-                bq[0] = read_b_frag<PREC>(sm, PN_BADDR(j));
-            }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[ct][pt] = mma(aq[s % NA][ct], bq[DB > 1 ? j % DB : 0], acc[ct][pt]);
-            if (DB > 1) {
-                // pin the issue order (the scheduler otherwise sinks every prefetch down to its use)
-                if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);                 // weight loads
-                if (j + DB - 1 < NITEM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
-                __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);                              // CT MFMAs
-            }
+            for (int p2 = 0; p2 < PT; ++p2)              // switch half (and back to the first one after the second)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) baddr[p2][kx] ^= SUBX;
         }
+#undef PN_BADDRX
 #undef PN_BADDR
         if (more) {
             if (!P.lds_two) __syncthreads();             // single LDS image: wait for every wave's reads
-            if (MAXST > 0) { if (!(P.dbg & 2)) stage_store(nbuf); }
+            if (MAXST > 0) stage_store(nbuf);
             else stage_direct(chunk + 1, nbuf);
             __syncthreads();
         }
@@ -349,17 +377,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
 
     // ---- epilogue ------------------------------------------------------------------------------
     // The MFMA C layout gives each lane 4 channels of one pixel: stored directly that is an 8-B
-    // write per lane into 16 different 128-B lines per instruction (measured: 40 % of the forward).
-    // Instead the block transposes its (acc + bias) tile through LDS ([pixel slot][cout] f32, rows
-    // padded by 16 B against bank conflicts) and every thread then handles 8 consecutive channels of
-    // one pixel: one 16-B residual load, activation, one 16-B (bf16) / 32-B (f32) store -- whole
-    // lines per pixel.  The NCHW f32 outputs of the last layers are written pixel-major from the
-    // same tile.
+    // write per lane into 16 different 128-B lines per instruction.  Instead the block transposes
+    // its (acc + bias) tile through LDS ([pixel slot][cout] f32, rows padded by 16 B against bank
+    // conflicts) and every thread then handles 8 consecutive channels of one pixel: one 16-B
+    // residual load, activation, one 16-B (bf16) / 32-B (f32) store -- whole lines per pixel.  The
+    // NCHW f32 outputs of the last layers are written pixel-major from the same tile.
     constexpr int BC = WC * CT * 16;
     constexpr int ROWB = BC * 4 + 16;
     constexpr int G = BC / 8;                        // 8-channel groups per pixel (power of two)
     const int act = P.act;
-    if (P.dbg & 4) return;
     __syncthreads();                                 // every wave is done with the halo image
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -373,19 +399,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     }
     __syncthreads();
     if (P.out) {
+        // 32-bit element offsets from scalar tensor bases (tensors are far below 2^31 elements)
+        const PN_GLOBAL T *res_base = (const PN_GLOBAL T *)P.res + P.res_coff + cb * BC;
+        PN_GLOBAL T *out_base = (PN_GLOBAL T *)P.out + P.out_coff + cb * BC;
+        const int pix0 = (b * P.Ho + oy0) * Wo + ox0;
         for (int i = tid; i < npix * G; i += 256) {
             const int slot = i / G, cg = i % G;
             const int co = cb * BC + cg * 8;
             if (co >= P.cout) continue;
             const int ry = (int)(((float)slot + 0.5f) * inv_wc);
-            const int rx = ox0 + (slot - ry * Wc);
-            const size_t opix = (size_t)(b * P.Ho + oy0 + ry) * Wo + rx;
+            const int opix = pix0 + ry * Wo + (slot - ry * Wc);
             const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + slot * ROWB + cg * 32);
             const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + slot * ROWB + cg * 32 + 16);
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const bool full = co + 7 < P.cout;
             if (P.res) {
-                const PN_GLOBAL T *rp = (const PN_GLOBAL T *)P.res + opix * P.res_cs + P.res_coff + co;
+                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * P.res_cs + cg * 8);
                 if (full) {
                     T rv[8];
                     if (sizeof(T) == 2) {
@@ -403,8 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = pn_activate(v[k], act, co + k, P.yolo_naf);
-            PN_GLOBAL T *op = (PN_GLOBAL T *)P.out + opix * P.out_cs + P.out_coff + co;
-            if (P.dbg & 8) { if (v[0] == 1234.5f) op[0] = (T)v[1]; continue; }   // timing ablation: no stores
+            PN_GLOBAL T *op = out_base + (unsigned)(opix * P.out_cs + cg * 8);
             if (full) {
                 T ov[8];
 #pragma unroll

@@ -198,9 +198,9 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     float *h32 = reinterpret_cast<float *>(host.data());
     for (int ct = 0; ct < ctiles; ++ct)
         for (int chunk = 0; chunk < cs.cin_chunks; ++chunk)
-            for (int tap = 0; tap < KK; ++tap)
-                for (int sub = 0; sub < 2; ++sub) {
-                    const size_t kstep = (size_t)(chunk * KK + tap) * 2 + sub;
+            for (int sub = 0; sub < 2; ++sub)
+                for (int tap = 0; tap < KK; ++tap) {
+                    const size_t kstep = (size_t)(chunk * 2 + sub) * KK + tap;   // kernel k order: (chunk, half, tap)
                     const size_t frag = (size_t)ct * ksteps + kstep;
                     for (int lane = 0; lane < 64; ++lane) {
                         const int co = ct * 16 + (lane & 15), q = lane >> 4;
@@ -484,7 +484,6 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.nblocks = B * P.tiles_per_img * P.cout_blocks;
             P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
             P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
-            P.dbg = getenv("POPNET_DBG") ? atoi(getenv("POPNET_DBG")) : 0;
             P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
             if (P.lds_two) two_bufs = true;
             max_blocks = std::max(max_blocks, P.nblocks);

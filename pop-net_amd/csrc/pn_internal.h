@@ -63,7 +63,6 @@ struct ConvProblem {
     int ksteps;            // cin_chunks * KS*KS * 2   (k32 steps per cout tile in wpack)
     int lds_buf_bytes;     // bytes of one LDS halo image
     int lds_two;           // 1: a second image follows (double-buffered chunks), 0: single image
-    int dbg;               // timing ablations only ($POPNET_DBG): 1 = reuse first weight fragments, 2 = stage chunk 0 only, 4 = skip epilogue stores
 };
 
 // Tile configuration ids (see conv_mfma.hip).
