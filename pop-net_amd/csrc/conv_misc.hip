@@ -67,11 +67,81 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const float *__restrict__ 
     }
 }
 
-int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const float *bias, void *out,
+// ---------------------------------------------------------------------------------------------
+// Stem on the matrix cores (bf16 mode).  D[cout][pixel] = sum_k W[cout][k] X[k][pixel] with
+// k = ky*8 + kx' (kx' = kx + 1: tap column 0 and tap row 7 carry zero weights), i.e. K = 64 = two
+// v_mfma_f32_16x16x32_bf16 steps.  Shifting the window by one column makes every lane's 8-tap row
+// segment start at an EVEN input column (2*ox - 4): four 4-byte-aligned ds_read_b32 build the B
+// fragment straight from a bf16 copy of the input tile -- no im2col buffer.  The 8 weight fragments
+// (64 couts x 64 k) live in registers for the whole block.  Tile rows of cout tile t are permuted
+// (row 4q+r <-> cout 16q+4t+r) so that a lane's 16 accumulators are 16 CONSECUTIVE channels of its
+// pixel: two 16-B NHWC stores.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int stem_u32x4;
+#define STEM_PITCH 96      // bf16 elements per LDS row: PITCH/2 = 48 = 16 (mod 32) -> the two row groups of a ds_read_b32 phase hit disjoint banks
+
+__global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wfrag,
+                                                            const float *__restrict__ bias, __bf16 *__restrict__ out,
+                                                            int H, int W, int Ho, int Wo, int out_cs) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[38 * STEM_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 4;
+    const float *xb = x + (size_t)b * H * W;
+    for (int i = tid; i < 38 * 38; i += 256) {
+        const int r = i / 38, cc = i - r * 38;
+        const int iy = iy0 + r, ix = ix0 + cc;
+        float v = 0.f;
+        if (r < 37 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[(size_t)iy * W + ix];
+        tile[r * STEM_PITCH + cc] = (__bf16)v;          // row 37 (tap row 7) is zero: its weights are zero, the data must be finite
+    }
+    stem_bf16x8 aw[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) aw[t][s] = *reinterpret_cast<const stem_bf16x8 *>(wfrag + ((t * 2 + s) * 64 + lane) * 8);
+    float bs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bs[i] = bias[16 * q + i];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int ry = wave * 4 + rr;                    // output row of this pixel tile (16 pixels: ox0 .. ox0+15)
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned *src = reinterpret_cast<const unsigned *>(&tile[(2 * ry + 4 * s + q) * STEM_PITCH + 2 * c]);
+            stem_u32x4 raw = {src[0], src[1], src[2], src[3]};
+            stem_bf16x8 bf = *reinterpret_cast<stem_bf16x8 *>(&raw);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t][s], bf, acc[t], 0, 0, 0);
+        }
+        const int oy = oy0 + ry, ox = ox0 + c;
+        if (oy < Ho && ox < Wo) {
+            __bf16 o[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[t][r] + bs[4 * t + r];
+                    o[4 * t + r] = (__bf16)(v > 0.f ? v : 0.f);
+                }
+            __bf16 *op = out + ((size_t)(b * Ho + oy) * Wo + ox) * out_cs + 16 * q;
+            reinterpret_cast<stem_u32x4 *>(op)[0] = reinterpret_cast<stem_u32x4 *>(o)[0];
+            reinterpret_cast<stem_u32x4 *>(op)[1] = reinterpret_cast<stem_u32x4 *>(o)[1];
+        }
+    }
+}
+
+int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const void *wfrag, const float *bias, void *out,
                    int B, int H, int W, int Ho, int Wo, int out_cs, hipStream_t stream) {
     dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B), block(256);
     if (prec == PN_PREC_BF16)
-        hipLaunchKernelGGL(stem7x7_kernel<__bf16>, grid, block, 0, stream, x, w, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs);
+        hipLaunchKernelGGL(stem7x7_mfma_kernel, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs);
     else
         hipLaunchKernelGGL(stem7x7_kernel<float>, grid, block, 0, stream, x, w, bias, (float *)out, H, W, Ho, Wo, out_cs);
     PN_HIP_CHECK(ctx, hipGetLastError());

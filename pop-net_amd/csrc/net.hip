@@ -56,6 +56,7 @@ struct Step {
     // STEM
     int out_buf = -1;
     float *stem_w = nullptr, *stem_b = nullptr;
+    void *stem_wfrag = nullptr;      // bf16 MFMA fragments of the same weights
     // POOL
     int mode = 0, in_buf = -1, C = 0, out_coff = 0;
     // CONV: indices into pn_net::convs, all sharing one kernel instantiation
@@ -307,6 +308,23 @@ int add_stem(pn_net *n, int out_buf) {
     if (int rc = dev_alloc(n, (void **)&st.stem_b, hb.size() * 4, false)) return rc;
     PN_HIP_CHECK(ctx, hipMemcpy(st.stem_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     PN_HIP_CHECK(ctx, hipMemcpy(st.stem_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    {   // 8 A-fragments [cout tile t][k-step s][lane][8]: tile row 4q'+r' <-> cout 16q'+4t+r', k = ky*8 + kx+1
+        std::vector<uint16_t> hf(8 * 64 * 8, 0);
+        for (int t = 0; t < 4; ++t)
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r16 = lane & 15, qa = lane >> 4;
+                    const int co = 16 * (r16 >> 2) + 4 * t + (r16 & 3);
+                    const int ky = 4 * s2 + qa;
+                    for (int j = 0; j < 8; ++j) {
+                        float v = 0.f;
+                        if (ky < 7 && j >= 1) v = hw[(ky * 7 + (j - 1)) * 64 + co];
+                        hf[((t * 2 + s2) * 64 + lane) * 8 + j] = f32_to_bf16(v);
+                    }
+                }
+        if (int rc = dev_alloc(n, &st.stem_wfrag, hf.size() * 2, false)) return rc;
+        PN_HIP_CHECK(ctx, hipMemcpy(st.stem_wfrag, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+    }
     n->steps.push_back(st);
     n->flops_per_frame += 2.0 * n->bufs[out_buf].H * n->bufs[out_buf].W * 64.0 * 49.0;
     return PN_OK;
@@ -534,7 +552,7 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         }
         if (st.type == Step::STEM) {
             const Buf &ob = n->bufs[st.out_buf];
-            rc = pn_launch_stem(ctx, n->prec, x, st.stem_w, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, stream);
+            rc = pn_launch_stem(ctx, n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, stream);
         } else if (st.type == Step::POOL) {
             const Buf &ib = n->bufs[st.in_buf], &ob = n->bufs[st.out_buf];
             rc = pn_launch_pool(ctx, n->prec, st.mode, ib.p, ob.p, B, ib.H, ib.W, st.C, ib.C, ob.C, st.out_coff, stream);
