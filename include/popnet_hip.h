@@ -191,12 +191,19 @@ typedef struct pn_yolo_frame {
     float   bbox[PN_YOLO_MAX_DET][5];                 /* x1, y1, x2, y2, conf (pixels) */
     float   human[PN_YOLO_MAX_DET][PN_NUM_JOINTS][3]; /* x, y (pixels), Z (metres) */
     int32_t visibility[PN_YOLO_MAX_DET][PN_NUM_JOINTS];
+    /* per-frame glue of tpm/evaluate/evaluation_yolo_posenet_kdh3d_mpreal.py:182-217 (float32, as the
+     * script computes it): joints rescaled to the original frame and back-projected; part confidence =
+     * bbox[4] for every joint.  Filled when pn_parse_yolo is given a glue configuration. */
+    float   joints_2d[PN_YOLO_MAX_DET][PN_NUM_JOINTS][2];
+    float   joints_3d[PN_YOLO_MAX_DET][PN_NUM_JOINTS][3];
+    float   bbox_org[PN_YOLO_MAX_DET][4];             /* box corners rescaled to the original frame (:197-200) */
 } pn_yolo_frame;
 
 int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w,
                   const float *anchors_wh, int num_anchors, int num_joints, int w_out, int h_out,
                   float depth_mean, float depth_std, float conf_threshold, float nms_threshold,
-                  int vis_margin, pn_yolo_frame *frames_dev, void *hip_stream);
+                  int vis_margin, const pn_parse_cfg *glue /* may be NULL: input_size, w_org, h_org, intrinsics */,
+                  pn_yolo_frame *frames_dev, void *hip_stream);
 
 size_t pn_sizeof_yolo_frame(void);
 

@@ -106,3 +106,31 @@ def parse_prior_pose(posemaps, anchors, num_joints, w_out, h_out, depth_mean, de
         humans_out.append(hb)
         vis_out.append(vb)
     return bboxes_out, humans_out, vis_out
+
+
+def frame_glue(bboxes_b, humans_b, num_joints, input_size, w_org, h_org, intrinsics):
+    """Per-frame glue of tpm/evaluate/evaluation_yolo_posenet_kdh3d_mpreal.py:182-217 for ONE image of
+    parse_prior_pose's output: joints (and box corners, :197-200) rescaled to the original frame,
+    back-projected with pos_3d_from_2d_and_depth (tpm/lib/utils/common.py:107-115), part confidence =
+    the box confidence repeated for every joint (:185-186).  float32 throughout except part_conf
+    (np.float = float64 of a float32 value), exactly as the script computes it.
+    Returns dict(humans_2d [n,J,2] f32, humans_3d [n,J,3] f32, part_conf [n,J] f64, bboxes [n,5] f32)."""
+    n = len(humans_b)
+    J = num_joints
+    h2 = np.zeros((n, J, 2), np.float32)
+    h3 = np.zeros((n, J, 3), np.float32)
+    bb = np.zeros((n, 5), np.float32)
+    conf = np.zeros((n, J), np.float64)
+    for i in range(n):
+        human = np.array(humans_b[i][:, :2])                        # float32 copy (:183,:192)
+        depth = humans_b[i][:, 2]
+        human[:, 0] = human[:, 0] / input_size * w_org               # :194
+        human[:, 1] = human[:, 1] / input_size * h_org               # :195
+        box = np.array(bboxes_b[i], dtype=np.float32)
+        box[0] = box[0] / input_size * w_org; box[2] = box[2] / input_size * w_org      # :197-198
+        box[1] = box[1] / input_size * h_org; box[3] = box[3] / input_size * h_org      # :199-200
+        X = (human[:, 0] - intrinsics['cx']) / intrinsics['fx'] * depth                  # common.py:113
+        Y = (human[:, 1] - intrinsics['cy']) / intrinsics['fy'] * depth                  # common.py:114
+        h2[i], h3[i], bb[i] = human, np.vstack([X, Y, depth]).T, box
+        conf[i] = float(bboxes_b[i][4])
+    return {"humans_2d": h2, "humans_3d": h3, "part_conf": conf, "bboxes": bb}

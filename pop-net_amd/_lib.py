@@ -58,6 +58,9 @@ YOLO_FRAME_DTYPE = np.dtype([
     ("bbox", np.float32, (PN_YOLO_MAX_DET, 5)),
     ("human", np.float32, (PN_YOLO_MAX_DET, PN_NUM_JOINTS, 3)),
     ("visibility", np.int32, (PN_YOLO_MAX_DET, PN_NUM_JOINTS)),
+    ("joints_2d", np.float32, (PN_YOLO_MAX_DET, PN_NUM_JOINTS, 2)),
+    ("joints_3d", np.float32, (PN_YOLO_MAX_DET, PN_NUM_JOINTS, 3)),
+    ("bbox_org", np.float32, (PN_YOLO_MAX_DET, 4)),
 ], align=True)
 
 _lib = None
@@ -83,7 +86,7 @@ _SIGNATURES = {
     "pn_parse_cfg_default": (None, [C.POINTER(ParseCfg)]),
     "pn_parse_paf": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
-    "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _vp]),
+    "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_sizeof_pose_frame": (_sz, []),
     "pn_sizeof_yolo_frame": (_sz, []),
     "pn_debug_cubic_coeffs": (None, [_f, C.POINTER(C.c_float)]),

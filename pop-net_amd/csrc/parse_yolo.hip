@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void parse_yolo_kernel(const float *__restrict
                                                           float aw0, float ah0, float aw1, float ah1, float aw2, float ah2,
                                                           float w_out, float h_out, float depth_mean, float depth_std,
                                                           float conf_thr, float nms_thr, float vis_margin,
-                                                          pn_yolo_frame *__restrict__ frames) {
+                                                          int glue, float g_in, float g_worg, float g_horg, float g_fx, float g_fy,
+                                                          float g_cx, float g_cy, pn_yolo_frame *__restrict__ frames) {
     __shared__ unsigned short s_cell[YMAXC];            // candidate -> a*hw + cell
     __shared__ float s_score[YMAXC];
     __shared__ float s_x1[YMAXC], s_y1[YMAXC], s_x2[YMAXC], s_y2[YMAXC];   // in sorted order
@@ -154,12 +155,23 @@ __global__ __launch_bounds__(256) void parse_yolo_kernel(const float *__restrict
                 b2 = b2 + b0; b3 = b3 + b1;
                 out.bbox[o][0] = b0; out.bbox[o][1] = b1; out.bbox[o][2] = b2; out.bbox[o][3] = b3;
                 out.bbox[o][4] = f[4 * hw];
+                if (glue) {
+                    out.bbox_org[o][0] = b0 / g_in * g_worg; out.bbox_org[o][2] = b2 / g_in * g_worg;
+                    out.bbox_org[o][1] = b1 / g_in * g_horg; out.bbox_org[o][3] = b3 / g_in * g_horg;
+                }
                 const float awh = aw / 2.0f, ahh = ah / 2.0f;
                 for (int jn = 0; jn < J; ++jn) {
                     float x = ((f[(size_t)(5 + jn) * hw] * awh + gx) / fw) * w_out;
                     float y = ((f[(size_t)(5 + J + jn) * hw] * ahh + gy) / fh) * h_out;
                     float zz = f[(size_t)(5 + 2 * J + jn) * hw] * depth_std + depth_mean;
                     out.human[o][jn][0] = x; out.human[o][jn][1] = y; out.human[o][jn][2] = zz;
+                    if (glue) {      // evaluation_yolo_posenet_kdh3d_mpreal.py:194-195, common.py:107-115, all float32
+                        const float x2 = x / g_in * g_worg, y2 = y / g_in * g_horg;
+                        out.joints_2d[o][jn][0] = x2; out.joints_2d[o][jn][1] = y2;
+                        out.joints_3d[o][jn][0] = (x2 - g_cx) / g_fx * zz;
+                        out.joints_3d[o][jn][1] = (y2 - g_cy) / g_fy * zz;
+                        out.joints_3d[o][jn][2] = zz;
+                    }
                     out.visibility[o][jn] = (x >= 0.f + vis_margin && x <= w_out - 1.f - vis_margin &&
                                              y >= 0.f + vis_margin && y <= h_out - 1.f - vis_margin) ? 1 : 0;
                 }
@@ -178,8 +190,8 @@ __global__ __launch_bounds__(256) void parse_yolo_kernel(const float *__restrict
 
 extern "C" int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w, const float *anchors_wh,
                              int num_anchors, int num_joints, int w_out, int h_out, float depth_mean, float depth_std,
-                             float conf_threshold, float nms_threshold, int vis_margin, pn_yolo_frame *frames_dev,
-                             void *hip_stream) {
+                             float conf_threshold, float nms_threshold, int vis_margin, const pn_parse_cfg *glue,
+                             pn_yolo_frame *frames_dev, void *hip_stream) {
     if (!ctx) return PN_ERR_INVALID;
     if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
     if (!posemaps_dev || !anchors_wh || !frames_dev || B < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_parse_yolo: bad arguments");
@@ -190,7 +202,9 @@ extern "C" int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int 
     for (int i = 0; i < 2 * num_anchors; ++i) a[i] = anchors_wh[i];
     hipLaunchKernelGGL(parse_yolo_kernel, dim3(B), dim3(256), 0, (hipStream_t)hip_stream, posemaps_dev, h, w, num_anchors,
                        num_joints, a[0], a[1], a[2], a[3], a[4], a[5], (float)w_out, (float)h_out, depth_mean, depth_std,
-                       conf_threshold, nms_threshold, (float)vis_margin, frames_dev);
+                       conf_threshold, nms_threshold, (float)vis_margin, glue ? 1 : 0, glue ? (float)glue->input_size : 1.f,
+                       glue ? (float)glue->w_org : 1.f, glue ? (float)glue->h_org : 1.f, glue ? (float)glue->fx : 1.f,
+                       glue ? (float)glue->fy : 1.f, glue ? (float)glue->cx : 0.f, glue ? (float)glue->cy : 0.f, frames_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }

@@ -91,6 +91,108 @@ class PoseEngine:
         return records_to_numpy(self.predict(depth))
 
 
+class YoloEngine:
+    """Batched Yolo-Pose+ twin of PoseEngine: depth frames -> pn_preprocess -> pn_yolo_forward ->
+    pn_parse_yolo (decode + box NMS + skeletons + the evaluation script's rescale / back-projection)
+    -> pn_yolo_frame records.  Per-batch body of
+    tpm/evaluate/evaluation_yolo_posenet_kdh3d_mpreal.py:137-217 minus Python."""
+
+    def __init__(self, precision="bf16", state_dict=None, device=None, max_batch=32, input_size=224,
+                 w_org=480, h_org=640, intrinsics=INTRINSICS, weight_seed=1, anchors=None,
+                 conf_threshold=0.5, nms_threshold=0.5):
+        from .config import YOLO_ANCHORS
+        from .network.yolo_posenet import YoloPoseNet
+        if not torch.cuda.is_available():
+            raise _lib.PopnetError("YoloEngine needs a GPU: the HIP path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_batch, self.S = int(max_batch), int(input_size)
+        self.anchors = list(YOLO_ANCHORS if anchors is None else anchors)
+        self.model = YoloPoseNet(15, input_dim=1, anchors=self.anchors).eval()
+        if state_dict is None:
+            synth.load_synth_weights(self.model, seed=weight_seed)
+            calibrate_yolo_conf(self.model, self.device)
+        else:
+            self.model.load_state_dict(state_dict)
+        self.model.precision = precision
+        self.ctx = _lib.Context.for_device(self.device.index)
+        self.L = _lib.lib()
+        self.net = self.model._compile(self.device, self.max_batch, self.S, self.S)
+        self.cfg = make_parse_cfg(default_cfg(), input_size=self.S, w_org=w_org, h_org=h_org, intrinsics=intrinsics,
+                                  depth_mean=DEPTH_MEAN, depth_std=DEPTH_STD)
+        self.conf_threshold, self.nms_threshold = float(conf_threshold), float(nms_threshold)
+        flat = [float(v) for a in self.anchors for v in a]
+        self._anchors_c = (C.c_float * len(flat))(*flat)
+        d = self.device
+        self.x = torch.empty((self.max_batch, 1, self.S, self.S), device=d, dtype=torch.float32)
+        self.out = torch.empty((self.max_batch, len(self.anchors) * 50, self.S // 16, self.S // 16), device=d,
+                               dtype=torch.float32)
+        self.frames = torch.empty((self.max_batch, _lib.YOLO_FRAME_DTYPE.itemsize), device=d, dtype=torch.uint8)
+        self.flops_per_frame = self.L.pn_net_flops_per_frame(self.net)
+
+    preprocess = PoseEngine.preprocess
+
+    def forward(self, B):
+        self.ctx.check(self.L.pn_yolo_forward(self.net, C.c_void_p(self.x.data_ptr()), B, C.c_void_p(self.out.data_ptr()),
+                                              _lib.current_stream_ptr(self.device)), "pn_yolo_forward")
+
+    def parse(self, B, frames=None):
+        frames = self.frames if frames is None else frames
+        h = self.S // 16
+        self.ctx.check(self.L.pn_parse_yolo(self.ctx.handle, C.c_void_p(self.out.data_ptr()), B, h, h, self._anchors_c,
+                                            len(self.anchors), 15, self.S, self.S, float(DEPTH_MEAN), float(DEPTH_STD),
+                                            self.conf_threshold, self.nms_threshold, 0, C.byref(self.cfg),
+                                            C.c_void_p(frames.data_ptr()), _lib.current_stream_ptr(self.device)),
+                       "pn_parse_yolo")
+
+    def predict(self, depth, frames=None):
+        """depth [B,H,W] CUDA f16/f32 -> device uint8 tensor [B, sizeof(pn_yolo_frame)] (no sync)."""
+        B = self.preprocess(depth)
+        self.forward(B)
+        self.parse(B, frames)
+        return (self.frames if frames is None else frames)[:B]
+
+    def predict_host(self, depth):
+        return self.predict(depth).cpu().numpy().view(_lib.YOLO_FRAME_DTYPE).reshape(-1)
+
+
+def calibrate_yolo_conf(model, device=None, frac=0.012, calib_frames=8, seed=99):
+    """Synthetic-checkpoint calibration for YoloPoseNet (bench / smoke only; never applied to user
+    weights).  Seeded random weights put every cell's confidence near sigmoid(0) = 0.5, i.e. ~200
+    candidate boxes per frame.  The last conv has no bias, so the two confidence filters (channels 4
+    and 54) are shifted by a constant -delta on every tap: delta is grid-searched on a seeded
+    calibration batch (fp32 forward of the HIP path itself) so ~frac of the cells pass conf > 0.5."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    depth = torch.from_numpy(synth.synth_depth(calib_frames, seed=seed)).to(device)
+    ctx = _lib.Context.for_device(device.index)
+    x = torch.empty((calib_frames, 1, 224, 224), device=device, dtype=torch.float32)
+    ctx.check(_lib.lib().pn_preprocess(ctx.handle, C.c_void_p(depth.data_ptr()), _lib.PN_DEPTH_F16, calib_frames,
+                                       depth.shape[1], depth.shape[2], C.c_void_p(x.data_ptr()), 224, float(DEPTH_MAX),
+                                       float(DEPTH_MEAN), float(DEPTH_STD), _lib.current_stream_ptr(device)), "pn_preprocess")
+    prec = model.precision
+    model.precision = "fp32"
+    w0 = model.model2_4[0].weight.detach().clone()
+
+    def frac_at(delta):
+        with torch.no_grad():
+            model.model2_4[0].weight.copy_(w0)
+            model.model2_4[0].weight[[4, 54]] -= delta
+        model.invalidate()
+        out = model(x)
+        return float((out[:, [4, 54]] > 0.5).float().mean())
+
+    lo, hi = 0.0, 0.2
+    for _ in range(12):                      # fraction above 0.5 falls as delta grows (inputs are mostly positive)
+        mid = 0.5 * (lo + hi)
+        if frac_at(mid) > frac:
+            lo = mid
+        else:
+            hi = mid
+    frac_at(hi)
+    model.precision = prec
+    model.invalidate()
+    return model
+
+
 def records_to_numpy(frames_dev):
     return frames_dev.cpu().numpy().view(_lib.POSE_FRAME_DTYPE).reshape(-1)
 

@@ -16,22 +16,29 @@ from .. import _lib
 
 
 def parse_yolo_batch(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold,
-                     nms_threshold, vis_margin=0):
-    """posemaps: float32 CUDA tensor [B, A*(5+3J), h, w].  Returns host records (structured array)."""
+                     nms_threshold, vis_margin=0, glue_cfg=None, frames=None):
+    """posemaps: float32 CUDA tensor [B, A*(5+3J), h, w].  Returns host records (structured array), or --
+    when a device `frames` buffer is given -- leaves them on the device (no synchronisation).  glue_cfg
+    (a _lib.ParseCfg) additionally fills joints_2d / joints_3d / bbox_org like the evaluation script."""
     _lib.require_cuda_tensor(posemaps, "posemaps")
     if posemaps.dim() == 3:
         posemaps = posemaps.unsqueeze(0)
     pm = posemaps.contiguous().float()
     B, _, h, w = pm.shape
     dev = pm.device
-    frames = torch.empty((B, _lib.YOLO_FRAME_DTYPE.itemsize), device=dev, dtype=torch.uint8)
+    keep_on_device = frames is not None
+    if frames is None:
+        frames = torch.empty((B, _lib.YOLO_FRAME_DTYPE.itemsize), device=dev, dtype=torch.uint8)
     flat = [float(v) for a in anchors for v in a]
     arr = (C.c_float * len(flat))(*flat)
     ctx = _lib.Context.for_device(dev.index)
     ctx.check(_lib.lib().pn_parse_yolo(ctx.handle, C.c_void_p(pm.data_ptr()), B, h, w, arr, len(anchors), num_joints,
                                        int(w_out), int(h_out), float(depth_mean), float(depth_std), float(conf_threshold),
-                                       float(nms_threshold), int(vis_margin), C.c_void_p(frames.data_ptr()),
+                                       float(nms_threshold), int(vis_margin), C.byref(glue_cfg) if glue_cfg is not None else None,
+                                       C.c_void_p(frames.data_ptr()),
                                        _lib.current_stream_ptr(dev)), "pn_parse_yolo")
+    if keep_on_device:
+        return frames[:B]
     return frames.cpu().numpy().view(_lib.YOLO_FRAME_DTYPE).reshape(B)
 
 

@@ -24,6 +24,7 @@ def golden():
         pafprocess = np.load(os.path.join(GOLDEN, "pafprocess.npz"))
         keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
         script = json.load(open(os.path.join(GOLDEN, "script_eval_data.json")))
+        script_yolo = json.load(open(os.path.join(GOLDEN, "script_eval_data_yolo.json")))
     return G
 
 

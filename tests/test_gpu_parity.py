@@ -272,6 +272,87 @@ def test_yolo_decode_dense_batch_vs_oracle(gpu):
             assert np.array_equal(np.array(v[i]), np.array(rv[i]))
 
 
+def test_yolo_glue_bit_exact_vs_oracle(gpu):
+    """joints_2d / joints_3d / bbox_org of pn_yolo_frame == the oracle restatement of the evaluation
+    script's per-frame glue (float32), bit for bit."""
+    from oracle import parse_yolo as O
+    from popnet_amd.config import INTRINSICS
+    from popnet_amd.utils.paf_to_pose import make_parse_cfg
+    from popnet_amd.utils.prior_pose_align import parse_yolo_batch
+    rng = np.random.default_rng(9)
+    pm = rng.uniform(-1, 1, (8, 100, 14, 14)).astype(np.float32)
+    pm[:, 4] = rng.uniform(0, 0.56, (8, 14, 14))
+    pm[:, 54] = rng.uniform(0, 0.53, (8, 14, 14))
+    pm[:, 2:4] = rng.uniform(0.5, 2, (8, 2, 14, 14))
+    pm[:, 52:54] = rng.uniform(0.5, 2, (8, 2, 14, 14))
+    rb, rh, _ = O.parse_prior_pose(pm.copy(), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    cfg = make_parse_cfg(None, input_size=224, w_org=480, h_org=640, intrinsics=INTRINSICS)
+    recs = parse_yolo_batch(torch.from_numpy(pm).to(gpu), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5, glue_cfg=cfg)
+    seen = 0
+    for i in range(8):
+        n = int(recs[i]["n_det"])
+        assert n == len(rb[i]) and int(recs[i]["status"]) == 0
+        if n:
+            g = O.frame_glue(rb[i], rh[i], 15, 224, 480, 640, INTRINSICS)
+            assert np.array_equal(recs[i]["joints_2d"][:n], g["humans_2d"])
+            assert np.array_equal(recs[i]["joints_3d"][:n], g["humans_3d"])
+            assert np.array_equal(recs[i]["bbox_org"][:n], g["bboxes"][:, :4])
+            assert np.array_equal(recs[i]["bbox"][:n, 4].astype(np.float64), g["part_conf"][:, 0])
+            seen += n
+    assert seen > 8
+
+
+def test_yolo_end_to_end_vs_reference_eval_script(gpu, golden):
+    """Depth frames -> YoloEngine (fp32 parity mode) == eval_data.json of the reference's own
+    evaluation_yolo_posenet_kdh3d_mpreal.py on the same frames and weights: same detections in the
+    same order, 3D joints within 1e-3 m (north_star tolerance), confidences 1e-4, 2D within 0.05 px (one unit
+    of the network's joint channel spans 6 cells x 16 px x 640/224 = 274 px, so the 2e-4 fp32 forward
+    tolerance maps to 0.05 px)."""
+    from popnet_amd.pipeline import YoloEngine
+    s = golden.script_yolo
+    sd = state_dict_from_keys(golden.keys["yolo_posenet"], seed=s["weight_seed"])
+    sd["model2_4.0.weight"][[4, 54]] -= np.float32(s["conf_weight_shift"])
+    eng = YoloEngine(precision="fp32", state_dict=sd, device=gpu, max_batch=2)
+    frames = synth.synth_depth(2, 640, 480, seed=s["depth_seed"])
+    recs = eng.predict_host(torch.from_numpy(frames).to(gpu))
+    total = 0
+    for b in range(2):
+        fr = recs[b]
+        n = int(fr["n_det"])
+        assert n == len(s["human_pred_set_2d"][b]) and int(fr["status"]) == 0
+        if n:
+            assert np.abs(fr["joints_2d"][:n] - np.array(s["human_pred_set_2d"][b])).max() < 5e-2
+            assert np.abs(fr["joints_3d"][:n] - np.array(s["human_pred_set_3d"][b])).max() < 1e-3
+            assert np.abs(fr["bbox"][:n, 4:5] - np.array(s["human_pred_set_part_conf"][b])).max() < 1e-4
+        total += n
+    assert total >= 2
+
+
+def test_yolo_engine_bf16_full_batch_decode_is_self_consistent(gpu):
+    """BASELINE configs[1] shape for Yolo-Pose+ (32 frames, bf16): the records must equal the ORACLE
+    decode of the map the HIP forward produced, bit for bit."""
+    from oracle import parse_yolo as O
+    from popnet_amd.config import INTRINSICS
+    from popnet_amd.pipeline import YoloEngine
+    eng = YoloEngine(precision="bf16", device=gpu, max_batch=32)
+    depth = torch.from_numpy(synth.synth_depth(32, 640, 480, seed=5)).to(gpu)
+    recs = eng.predict_host(depth)
+    out = eng.out.cpu().numpy()
+    assert np.isfinite(out).all()
+    rb, rh, rv = O.parse_prior_pose(out.copy(), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    ndet = 0
+    for b in range(32):
+        n = int(recs[b]["n_det"])
+        assert int(recs[b]["status"]) == 0 and n == len(rb[b])
+        if n:
+            g = O.frame_glue(rb[b], rh[b], 15, 224, 480, 640, INTRINSICS)
+            assert np.array_equal(recs[b]["bbox"][:n], np.array(rb[b]))
+            assert np.array_equal(recs[b]["human"][:n], np.array(rh[b]))
+            assert np.array_equal(recs[b]["joints_3d"][:n], g["humans_3d"])
+        ndet += n
+    assert 8 <= ndet <= 32 * 12, ndet
+
+
 # ---------------------------------------------------------------------------------------------
 # legacy pafprocess plug-in ABI
 # ---------------------------------------------------------------------------------------------

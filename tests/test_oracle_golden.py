@@ -105,6 +105,27 @@ def test_script_level_pipeline_matches_reference_eval_script(golden):
         assert np.allclose(np.array(rec["conf"]).reshape(-1, 15), np.array(s["human_pred_set_part_conf"][b]).reshape(-1, 15), atol=1e-6)
 
 
+def test_yolo_script_level_pipeline_matches_reference_eval_script(golden):
+    """preproc -> YoloPoseNet forward -> decode/NMS -> glue of the oracle == eval_data.json written by
+    the reference's evaluation_yolo_posenet_kdh3d_mpreal.py on the same two frames."""
+    from oracle import parse_yolo
+    from popnet_amd.config import INTRINSICS, YOLO_ANCHORS
+    s = golden.script_yolo
+    sd = state_dict_from_keys(golden.keys["yolo_posenet"], seed=s["weight_seed"])
+    sd["model2_4.0.weight"][[4, 54]] -= np.float32(s["conf_weight_shift"])
+    frames = synth.synth_depth(2, 640, 480, seed=s["depth_seed"])
+    x = torch.from_numpy(preproc.preprocess_batch(frames))
+    out = nets.yolo_posenet_forward(x, sd).numpy()
+    bb, hh, _ = parse_yolo.parse_prior_pose(out, YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    for b in range(2):
+        g = parse_yolo.frame_glue(bb[b], hh[b], 15, 224, 480, 640, INTRINSICS)
+        want2 = np.array(s["human_pred_set_2d"][b]).reshape(-1, 15, 2)
+        assert g["humans_2d"].shape == want2.shape
+        assert np.allclose(g["humans_2d"], want2, atol=2e-3)
+        assert np.allclose(g["humans_3d"], np.array(s["human_pred_set_3d"][b]).reshape(-1, 15, 3), atol=1e-4)
+        assert np.allclose(g["part_conf"], np.array(s["human_pred_set_part_conf"][b]).reshape(-1, 15), atol=1e-5)
+
+
 def test_bicubic_point_evaluation_equals_materialised_upsample():
     rng = np.random.default_rng(3)
     a = rng.standard_normal((28, 28)).astype(np.float32)
