@@ -1,0 +1,7 @@
+// conv3_kernel instantiations, share 0 of 3 (128-cout blocks).
+#include "conv3_kernel.h"
+
+int pn_launch_conv3_part0(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
+    PN3_CASE(3, 4, 1, 1) PN3_CASE(3, 4, 1, 2) PN3_CASE(1, 4, 1, 1)
+    return 1;
+}

@@ -1,0 +1,300 @@
+// bf16 3x3 / 1x1 stride-1 "same" convolution on the CDNA4 matrix cores, high-occupancy variant.
+//
+// Same math, weight packing and epilogue contract as conv_mfma_kernel.h (which stays the generic
+// kernel: fp32 parity mode, stride 2, odd shapes); this one is what the bf16 perf path runs for
+// every stride-1 layer whose map splits into <= 30-column strips.  It replaces the same reference
+// code (tpm/lib/network/rtpose_light3d.py:24-72,222-246,335-350; yolo_posenet.py:101-126;
+// resnet.py:27-56).  What differs, and why (profiles/README.md, round-1 timeline stamps):
+//   * 4 waves per SIMD instead of 2 (<= 128 VGPRs): a block's fixed latencies (first halo fetch,
+//     chunk hand-over, epilogue burst) overlap with the MFMAs of the three other blocks of the CU.
+//   * LDS halo image is PIECE-MAJOR: [8 channel pieces of 16 B][halo row][32 px][16 B].  The 16
+//     lanes one ds_read_b128 phase serves read 16 consecutive 16-B entries (conflict-free with no
+//     XOR swizzle), so tap (ky,kx) and the 32-channel half are IMMEDIATE offsets of one address
+//     register per pixel tile (7 VGPRs instead of 42).
+//   * The halo is filled by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write.
+//     One wave instruction fills 2 halo rows of one piece plane; out-of-image pixels read a zero
+//     page that lives at the end of every activation buffer (ConvProblem::in_zero_off).
+//   * One LDS image per block (24.5 KB for a 4-row strip tile): the chunk hand-over stalls this
+//     block only; occupancy hides it.
+//   * Weights: global -> VGPR fragments through a 3-slot queue (2 k-steps ahead is enough at 4
+//     waves per SIMD).
+#pragma once
+#include "conv_mfma_kernel.h"
+
+#ifndef PN_CONV3_OCC
+#define PN_CONV3_OCC 4
+#endif
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_dst, lds_dst + 1024).
+// M0 is written in the same statement that uses it (the compiler does not preserve it around asm).
+__device__ __forceinline__ void pn_glds16(gcptr src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+
+template <int KS, int WC, int WP, int NBUF>
+__global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void conv3_kernel(const ConvProblem *__restrict__ probs) {
+    typedef __bf16 T;
+    typedef Elem<PN_PREC_BF16>::Frag Frag;
+    constexpr int CT = 2, PT = 7, NT = WC * WP * 64, NW = WC * WP;
+    constexpr int KK = KS * KS, PAD = KS / 2;
+    constexpr int PITCH = 32;                          // halo pixels per LDS row
+    constexpr int HR = 4 * WP + KS - 1 + ((KS - 1) & 1 ? 1 : 0);   // halo rows (even: one DMA fills two rows)
+    constexpr int PS = HR * PITCH * 16;                // bytes of one piece plane (multiple of 256)
+    constexpr int NG = 8 * (HR / 2);                   // DMA instructions per chunk, spread over the waves
+    constexpr int FRAGB = 1024;
+    constexpr int NSTEP = KK * 2;
+#ifndef PN_CONV3_NA2
+#define PN_CONV3_NA2 6
+#endif
+    constexpr int NA = KS == 1 ? 2 : (NBUF == 2 ? PN_CONV3_NA2 : 3);   // NSTEP % NA == 0: the queue slot of a k-step must not depend on the chunk
+    static_assert(NSTEP % NA == 0, "weight queue depth must divide the k-steps of a chunk");
+    constexpr int IMG = 8 * PS;                        // bytes of one halo image
+    constexpr int NITEM = NSTEP * PT;
+    constexpr int DB = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const ConvProblem &P = probs[blockIdx.y];
+    if ((int)blockIdx.x >= P.nblocks) return;
+    int bx;
+    {   // XCD-aware remap, see conv_mfma_kernel.h
+        const int nb = P.nblocks, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qq = nb >> 3, rr = nb & 7;
+        bx = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int tid = threadIdx.x;
+    PN_STAMP_AT(0);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int c = lane & 15, q = lane >> 4;
+
+    const int cb = bx % P.cout_blocks;
+    const int tt = bx / P.cout_blocks;
+    const int tile = tt % P.tiles_per_img;
+    const int b = tt / P.tiles_per_img;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int oy0 = ty * P.R, ox0 = tx * P.Wt;
+    const int R = min(P.R, P.Ho - oy0);
+    const int Wo = P.Wo;
+    const int Wc = min(P.Wt, Wo - ox0);
+    const int npix = R * Wc;
+    const int HC = Wc + KS - 1;
+    const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
+    const float inv_wc = 1.0f / (float)Wc;
+    const int nchunks = P.cin_chunks;
+
+    // ---- weight stream: scalar base per cout tile + lane offset; first NA-1 k-steps in flight ----
+    const int ctile0 = (cb * WC + wc) * CT;
+    gcptr wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wbase[ct] = (gcptr)P.wpack + (size_t)(ctile0 + ct) * P.ksteps * FRAGB;
+    const unsigned wlane = (unsigned)lane * 16u;
+    Frag aq[NA][CT];
+#pragma unroll
+    for (int d = 0; d < NA - 1; ++d)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = load_a_frag2<PN_PREC_BF16>(wbase[ct] + d * FRAGB, wlane);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wbase[ct] += (NA - 1) * FRAGB;
+
+    // ---- halo DMA: instruction n = wave * NGW + j fills rows (2i, 2i+1) of piece plane pc ----
+    constexpr int NGW = (NG + NW - 1) / NW;
+    gcptr img = (gcptr)P.in + ((size_t)b * P.H * P.W * P.in_cs + P.in_coff) * 2;
+    const unsigned zero_rel = P.in_zero_off - (unsigned)(((size_t)b * P.H * P.W * P.in_cs + P.in_coff) * 2);   // zero page relative to img
+    const int row_b = P.W * P.in_cs * 2, col_b = P.in_cs * 2;
+    const int hcol = lane & 31, hrow = lane >> 5;
+    const bool col_ok = hcol < HC && (unsigned)(ix0 + hcol) < (unsigned)P.W;
+    const unsigned coloff = (unsigned)((ix0 + hcol) * col_b);
+    const int Hin = P.H;
+    // Branch-free on purpose (a branch inside the unrolled K loop splits it into basic blocks and the
+    // compiler then drains the weight queue at every block boundary): an instruction that has nothing
+    // to fetch (`live` false, or n beyond the image) copies the zero page into a dump slot behind the images.
+    auto stage_one = [&](int chunk, int j, int bufoff, bool live) {   // j-th DMA instruction of this wave for `chunk`
+        const int n = wave * NGW + j;                    // wave-uniform
+        const bool on = live && n < NG;
+        const int pc = n / (HR / 2), i = n - pc * (HR / 2);
+        const int iy = iy0 + 2 * i + hrow;
+        const bool inb = (int)on & (int)col_ok & (int)((unsigned)iy < (unsigned)Hin);
+        unsigned off = (unsigned)(iy * row_b + pc * 16) + coloff;
+        asm volatile("" : "+v"(off));                    // materialise: the select below must stay a v_cndmask, not a branch
+        const unsigned zrel = zero_rel - (unsigned)(chunk * 128);
+        pn_glds16(img + chunk * 128 + (inb ? off : zrel),
+                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + pc * PS + i * (2 * PITCH * 16) : NBUF * IMG));
+    };
+    auto stage = [&](int chunk, int bufoff) {
+#pragma unroll
+        for (int j = 0; j < NGW; ++j) stage_one(chunk, j, bufoff, true);
+    };
+    stage(0, 0);
+
+    // ---- per-lane LDS read address of each pixel tile (tap / half are immediates) ----
+    int baddr[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int slot = (wp * PT + pt) * 16 + c;
+        int s = slot < npix ? slot : 0;
+        int ry = (int)(((float)s + 0.5f) * inv_wc);
+        int rx = s - ry * Wc;
+        baddr[pt] = q * PS + (ry * PITCH + rx) * 16;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    PN_STAMP_AT(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    PN_STAMP_AT(2);
+
+    static_assert(NBUF == 1 || NGW <= NSTEP, "the next chunk's DMA is spread one instruction per k-step");
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = NBUF == 2 ? (chunk & 1) * IMG : 0;
+        const int nxt = NBUF == 2 ? IMG - cur : 0;
+        const bool more = chunk + 1 < nchunks;
+        const char *sm = smem + cur;
+        // item j = (k-step s = half * KK + tap, pixel tile pt)
+#define PN3_OFF(j) ((((j) / PT) / KK) * 4 * PS + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 16)
+        Frag bq[DB];
+#pragma unroll
+        for (int j = 0; j < DB - 1; ++j) bq[j] = read_b_frag<PN_PREC_BF16>(sm + PN3_OFF(j), baddr[j % PT]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NITEM; ++j) {
+            const int s = j / PT, pt = j % PT;
+            if (pt == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {        // wpack ends with NA-1 spare fragments
+                    aq[(s + NA - 1) % NA][ct] = load_a_frag2<PN_PREC_BF16>(wbase[ct], wlane);
+                    wbase[ct] += FRAGB;
+                }
+                // double-buffered: the next chunk's image is fetched by ONE DMA instruction per k-step (the
+                // compiler does not count asm memory ops, so each one shortens the effective depth of the
+                // weight queue by half a k-step; a burst would stall the next weight wait for the whole DMA)
+                if (NBUF == 2 && s < NGW) stage_one(chunk + 1, s, nxt, more);
+            }
+            const int jr = j + DB - 1;
+            if (jr < NITEM) bq[jr % DB] = read_b_frag<PN_PREC_BF16>(sm + PN3_OFF(jr), baddr[jr % PT]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[ct][pt] = mma(aq[s % NA][ct], bq[j % DB], acc[ct][pt]);
+            if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);
+            if (jr < NITEM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+        }
+#undef PN3_OFF
+        PN_STAMP_AT(3 + 2 * (chunk & 3));
+        if (more) {
+            if (NBUF == 2) {
+                // every DMA is older than the 2*(NA-1) weight loads in flight: wait for exactly those
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA - 1)) : "memory");
+                __syncthreads();                         // image c+1 complete, image c free for chunk c+2
+            } else {
+                __syncthreads();                         // every wave is done reading this chunk's image
+                stage(chunk + 1, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        PN_STAMP_AT(4 + 2 * (chunk & 3));
+    }
+
+    // ---- epilogue: identical contract to conv_mfma_kernel.h (permuted cout rows, direct stores) ----
+    PN_STAMP_AT(11);
+    constexpr int LC = CT * 4;
+    const int cw = (cb * WC + wc) * (CT * 16) + LC * q;
+    const int cout = P.cout, act = P.act;
+    float bias[LC];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const f32x4 b4 = *reinterpret_cast<const PN_GLOBAL f32x4 *>((const PN_GLOBAL float *)P.bias + cw + 4 * ct);
+        bias[4 * ct + 0] = b4[0]; bias[4 * ct + 1] = b4[1]; bias[4 * ct + 2] = b4[2]; bias[4 * ct + 3] = b4[3];
+    }
+    const bool full = cw + LC <= cout;
+    const PN_GLOBAL T *res_base = P.res ? (const PN_GLOBAL T *)P.res + P.res_coff + cw : nullptr;
+    PN_GLOBAL T *out_base = P.out ? (PN_GLOBAL T *)P.out + P.out_coff + cw : nullptr;
+    PN_GLOBAL float *nchw = (PN_GLOBAL float *)P.out_nchw;
+    const int res_cs = P.res_cs, out_cs = P.out_cs, Ho = P.Ho, naf = P.yolo_naf;
+    const int pix0 = (b * Ho + oy0) * Wo + ox0;
+    auto finish = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int slot = (wp * PT + pt) * 16 + c;
+            if (slot >= npix || cw >= cout) continue;
+            const int ry = (int)(((float)slot + 0.5f) * inv_wc);
+            const int rx = slot - ry * Wc;
+            const int opix = pix0 + ry * Wo + rx;
+            float v[LC];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * ct + i] = acc[ct][pt][i] + bias[4 * ct + i];
+            if (res_base) {
+                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * res_cs);
+                if (full) {
+                    T rv[LC];
+                    *reinterpret_cast<u32x4 *>(rv) = *reinterpret_cast<const PN_GLOBAL u32x4 *>(rp);
+#pragma unroll
+                    for (int k = 0; k < LC; ++k) v[k] += (float)rv[k];
+                } else {
+                    for (int k = 0; k < LC; ++k)
+                        if (cw + k < cout) v[k] += (float)rp[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < LC; ++k) {
+                if (ACT == PN_ACT_NONE) {}
+                else if (ACT == PN_ACT_RELU) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                else if (ACT == PN_ACT_LEAKY) v[k] = v[k] > 0.f ? v[k] : v[k] * 0.1f;
+                else v[k] = pn_activate(v[k], act, cw + k, naf);
+            }
+            if (out_base) {
+                PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs);
+                if (full) {
+                    T ov[LC];
+#pragma unroll
+                    for (int k = 0; k < LC; ++k) ov[k] = (T)v[k];
+                    *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
+                } else {
+                    for (int k = 0; k < LC; ++k)
+                        if (cw + k < cout) op[k] = (T)v[k];
+                }
+            }
+            if (nchw) {
+                const size_t hw = (size_t)Ho * Wo;
+                PN_GLOBAL float *np = nchw + ((size_t)b * cout + cw) * hw + (size_t)(oy0 + ry) * Wo + (ox0 + rx);
+                for (int k = 0; k < LC; ++k)
+                    if (cw + k < cout) np[(size_t)k * hw] = v[k];
+            }
+        }
+    };
+    if (act == PN_ACT_RELU) finish(std::integral_constant<int, PN_ACT_RELU>{});
+    else if (act == PN_ACT_LEAKY) finish(std::integral_constant<int, PN_ACT_LEAKY>{});
+    else if (act == PN_ACT_NONE) finish(std::integral_constant<int, PN_ACT_NONE>{});
+    else finish(std::integral_constant<int, -1>{});
+    PN_STAMP_AT(12);
+}
+
+template <int KS, int WC, int WP, int NBUF>
+static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
+    auto kern = conv3_kernel<KS, WC, WP, NBUF>;
+    if (L.lds_bytes > 48 * 1024) {
+        static size_t configured = 0;   // per instantiation
+        if (configured < L.lds_bytes) {
+            PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes));
+            configured = L.lds_bytes;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(L.max_blocks, L.nprob), dim3(WC * WP * 64), L.lds_bytes, stream, L.probs_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+#define PN3_CASE(KS, WC, WP, NB) \
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
+int pn_launch_conv3_part0(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
+int pn_launch_conv3_part1(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
+int pn_launch_conv3_part2(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);

@@ -24,7 +24,11 @@
 //   * Epilogue fuses folded-BN bias, residual add, ReLU / LeakyReLU(0.1) / sigmoid casts, and
 //     can emit NHWC (next layer) and/or NCHW f32 (API boundary) in the same pass.
 #pragma once
+#include <type_traits>
 #include "pn_internal.h"
+#ifndef PN_STAMP_AT
+#define PN_STAMP_AT(i) do {} while (0)     // scripts/convlab.hip: in-kernel s_memtime timeline
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     }
 
     const int tid = threadIdx.x;
+    PN_STAMP_AT(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
@@ -316,7 +321,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     for (int ct = 0; ct < CT; ++ct) wbase[ct] += (NA - 1) * FRAGB;
     if (MAXST > 0) { stage_load(0); stage_store(buf0); }
     else stage_direct(0, buf0);
+    PN_STAMP_AT(1);
     __syncthreads();
+    PN_STAMP_AT(2);
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const char *sm = (chunk & 1) ? buf1 : buf0;
@@ -367,101 +374,115 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
         }
 #undef PN_BADDRX
 #undef PN_BADDR
+        PN_STAMP_AT(3 + 2 * (chunk & 3));
         if (more) {
             if (!P.lds_two) __syncthreads();             // single LDS image: wait for every wave's reads
             if (MAXST > 0) stage_store(nbuf);
             else stage_direct(chunk + 1, nbuf);
             __syncthreads();
         }
+        PN_STAMP_AT(4 + 2 * (chunk & 3));
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
-    // The MFMA C layout gives each lane 4 channels of one pixel: stored directly that is an 8-B
-    // write per lane into 16 different 128-B lines per instruction.  Instead the block transposes
-    // its (acc + bias) tile through LDS ([pixel slot][cout] f32, rows padded by 16 B against bank
-    // conflicts) and every thread then handles 8 consecutive channels of one pixel: one 16-B
-    // residual load, activation, one 16-B (bf16) / 32-B (f32) store -- whole lines per pixel.  The
-    // NCHW f32 outputs of the last layers are written pixel-major from the same tile.
+    // The MFMA C layout gives a lane 4 consecutive rows (couts) of one pixel per accumulator.  The
+    // packed weight rows are permuted on the host (net.hip::prepare_conv, pn_conv_row_channel) so
+    // that the CT accumulators of a lane together are LC = 4*CT CONSECUTIVE output channels: each
+    // lane adds the folded bias, the residual (one 16-B load), applies the activation and writes
+    // one 16-B (bf16, CT = 2) NHWC piece per pixel tile straight from registers -- no LDS transpose,
+    // no barrier; the four lane quarters of a wave cover 64 contiguous bytes of a pixel's line.
+    PN_STAMP_AT(11);
     constexpr int BC = WC * CT * 16;
-    constexpr int ROWB = BC * 4 + 16;
-    constexpr int G = BC / 8;                        // 8-channel groups per pixel (power of two)
-    const int act = P.act;
-    __syncthreads();                                 // every wave is done with the halo image
+    constexpr int LC = CT * 4;
+    const int cw = (cb * WC + wc) * (CT * 16) + LC * q;          // first output channel of this lane
+    const int cout = P.cout, act = P.act;
+    float bias[LC];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const int col = (wc * CT + ct) * 16 + 4 * q;
-        const f32x4 bias4 = *reinterpret_cast<const PN_GLOBAL f32x4 *>((const PN_GLOBAL float *)P.bias + cb * BC + col);
+        const f32x4 b4 = *reinterpret_cast<const PN_GLOBAL f32x4 *>((const PN_GLOBAL float *)P.bias + cw + 4 * ct);
+        bias[4 * ct + 0] = b4[0]; bias[4 * ct + 1] = b4[1]; bias[4 * ct + 2] = b4[2]; bias[4 * ct + 3] = b4[3];
+    }
+    (void)BC;
+    const bool full = cw + LC <= cout;
+    const PN_GLOBAL T *res_base = P.res ? (const PN_GLOBAL T *)P.res + P.res_coff + cw : nullptr;
+    PN_GLOBAL T *out_base = P.out ? (PN_GLOBAL T *)P.out + P.out_coff + cw : nullptr;
+    PN_GLOBAL float *nchw = (PN_GLOBAL float *)P.out_nchw;
+    const int res_cs = P.res_cs, out_cs = P.out_cs, Ho = P.Ho, naf = P.yolo_naf;
+    const int pix0 = (b * Ho + oy0) * Wo + ox0;
+    auto finish = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;            // -1: dispatch at run time (sigmoid casts: last layers only)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int slot = (wp * PT + pt) * 16 + c;
-            *reinterpret_cast<f32x4 *>(smem + slot * ROWB + col * 4) = acc[ct][pt] + bias4;
-        }
-    }
-    __syncthreads();
-    if (P.out) {
-        // 32-bit element offsets from scalar tensor bases (tensors are far below 2^31 elements)
-        const PN_GLOBAL T *res_base = (const PN_GLOBAL T *)P.res + P.res_coff + cb * BC;
-        PN_GLOBAL T *out_base = (PN_GLOBAL T *)P.out + P.out_coff + cb * BC;
-        const int pix0 = (b * P.Ho + oy0) * Wo + ox0;
-        for (int i = tid; i < npix * G; i += 256) {
-            const int slot = i / G, cg = i % G;
-            const int co = cb * BC + cg * 8;
-            if (co >= P.cout) continue;
+            if (slot >= npix || cw >= cout) continue;
             const int ry = (int)(((float)slot + 0.5f) * inv_wc);
-            const int opix = pix0 + ry * Wo + (slot - ry * Wc);
-            const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + slot * ROWB + cg * 32);
-            const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + slot * ROWB + cg * 32 + 16);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const bool full = co + 7 < P.cout;
-            if (P.res) {
-                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * P.res_cs + cg * 8);
+            const int rx = slot - ry * Wc;
+            const int opix = pix0 + ry * Wo + rx;
+            float v[LC];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * ct + i] = acc[ct][pt][i] + bias[4 * ct + i];
+            if (res_base) {
+                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * res_cs);
                 if (full) {
-                    T rv[8];
-                    if (sizeof(T) == 2) {
+                    T rv[LC];
+                    if (LC * sizeof(T) == 16) {
                         *reinterpret_cast<u32x4 *>(rv) = *reinterpret_cast<const PN_GLOBAL u32x4 *>(rp);
-                    } else {
+                    } else if (LC * sizeof(T) == 32) {
                         reinterpret_cast<u32x4 *>(rv)[0] = reinterpret_cast<const PN_GLOBAL u32x4 *>(rp)[0];
                         reinterpret_cast<u32x4 *>(rv)[1] = reinterpret_cast<const PN_GLOBAL u32x4 *>(rp)[1];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < LC; ++k) rv[k] = rp[k];
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
+                    for (int k = 0; k < LC; ++k) v[k] += (float)rv[k];
                 } else {
-                    for (int k = 0; k < 8; ++k)
-                        if (co + k < P.cout) v[k] += (float)rp[k];
+                    for (int k = 0; k < LC; ++k)
+                        if (cw + k < cout) v[k] += (float)rp[k];
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = pn_activate(v[k], act, co + k, P.yolo_naf);
-            PN_GLOBAL T *op = out_base + (unsigned)(opix * P.out_cs + cg * 8);
-            if (full) {
-                T ov[8];
+            for (int k = 0; k < LC; ++k) {
+                if (ACT == PN_ACT_NONE) {}
+                else if (ACT == PN_ACT_RELU) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                else if (ACT == PN_ACT_LEAKY) v[k] = v[k] > 0.f ? v[k] : v[k] * 0.1f;
+                else v[k] = pn_activate(v[k], act, cw + k, naf);
+            }
+            if (out_base) {
+                PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs);
+                if (full) {
+                    T ov[LC];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ov[k] = (T)v[k];
-                if (sizeof(T) == 2) {
-                    *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
+                    for (int k = 0; k < LC; ++k) ov[k] = (T)v[k];
+                    if (LC * sizeof(T) == 16) {
+                        *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
+                    } else if (LC * sizeof(T) == 32) {
+                        reinterpret_cast<PN_GLOBAL u32x4 *>(op)[0] = reinterpret_cast<u32x4 *>(ov)[0];
+                        reinterpret_cast<PN_GLOBAL u32x4 *>(op)[1] = reinterpret_cast<u32x4 *>(ov)[1];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < LC; ++k) op[k] = ov[k];
+                    }
                 } else {
-                    reinterpret_cast<PN_GLOBAL u32x4 *>(op)[0] = reinterpret_cast<u32x4 *>(ov)[0];
-                    reinterpret_cast<PN_GLOBAL u32x4 *>(op)[1] = reinterpret_cast<u32x4 *>(ov)[1];
+                    for (int k = 0; k < LC; ++k)
+                        if (cw + k < cout) op[k] = (T)v[k];
                 }
-            } else {
-                for (int k = 0; k < 8; ++k)
-                    if (co + k < P.cout) op[k] = (T)v[k];
+            }
+            if (nchw) {                                       // API-boundary layout: 16 lanes = 16 consecutive pixels of a plane
+                const size_t hw = (size_t)Ho * Wo;
+                PN_GLOBAL float *np = nchw + ((size_t)b * cout + cw) * hw + (size_t)(oy0 + ry) * Wo + (ox0 + rx);
+                for (int k = 0; k < LC; ++k)
+                    if (cw + k < cout) np[(size_t)k * hw] = v[k];
             }
         }
-    }
-    if (P.out_nchw) {
-        const int ncol = min(BC, P.cout - cb * BC);
-        const size_t hw = (size_t)P.Ho * Wo;
-        for (int i = tid; i < ncol * npix; i += 256) {
-            const int col = i / npix, slot = i - col * npix;
-            const int co = cb * BC + col;
-            const int ry = (int)(((float)slot + 0.5f) * inv_wc);
-            const int rx = ox0 + (slot - ry * Wc);
-            float v = *reinterpret_cast<const float *>(smem + slot * ROWB + col * 4);
-            v = pn_activate(v, act, co, P.yolo_naf);
-            ((PN_GLOBAL float *)P.out_nchw)[((size_t)b * P.cout + co) * hw + (size_t)(oy0 + ry) * Wo + rx] = v;
-        }
-    }
+    };
+    if (act == PN_ACT_RELU) finish(std::integral_constant<int, PN_ACT_RELU>{});
+    else if (act == PN_ACT_LEAKY) finish(std::integral_constant<int, PN_ACT_LEAKY>{});
+    else if (act == PN_ACT_NONE) finish(std::integral_constant<int, PN_ACT_NONE>{});
+    else finish(std::integral_constant<int, -1>{});
+    PN_STAMP_AT(12);
 }
 
 

@@ -46,6 +46,7 @@ struct ConvSpec {
     int cout = 0;
     // derived
     int cfg = 0, pitch = 0, R = 0, Wt = 0, cin_chunks = 0;
+    int kern = 0, wc = 0, wp = 0, nbuf = 0;   // kern 3: conv3_kernel<ks, wc, wp, nbuf> (bf16, stride 1, strip tiles)
     void *wpack = nullptr;
     float *bias = nullptr;
     double flops = 0;
@@ -187,7 +188,21 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     }
 
     cs.cfg = pick_cfg(cout);
-    const int BC = pn_cfg_couts(cs.cfg);
+    {   // bf16 stride-1 layers on maps that split into 24..30-column strips run conv3_kernel (conv3_kernel.h)
+        const Buf &ib0 = n->bufs[cs.in_buf];
+        const int segs = (ib0.W + 29) / 30, wt = (ib0.W + segs - 1) / segs;
+        if (n->prec == PN_PREC_BF16 && cs.stride == 1 && (ks == 3 || ks == 1) && wt >= 24 && cout > 32 && !getenv("POPNET_NO_CONV3")) {
+            cs.kern = 3;
+            cs.wc = cout > 64 ? 4 : (cout > 32 ? 2 : 1);
+            const long tiles112 = (long)n->max_batch * ((ib0.H + 3) / 4) * segs;           // 4-row strip tiles
+            cs.wp = (cs.wc == 2 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;           // big maps: 8-row tiles, 256 threads
+            const int hr = 4 * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
+            cs.nbuf = (cs.cin_chunks > 1 && ks == 3 && ngw <= 18) ? 2 : 1;
+            cs.Wt = wt;
+            cs.R = std::min(ib0.H, 4 * cs.wp);
+        }
+    }
+    const int BC = cs.kern == 3 ? cs.wc * 32 : pn_cfg_couts(cs.cfg);
     const int cout_pad = (cout + BC - 1) / BC * BC;
     const int ctiles = cout_pad / 16;
     const int KK = ks * ks;
@@ -204,7 +219,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
                     const size_t kstep = (size_t)(chunk * 2 + sub) * KK + tap;   // kernel k order: (chunk, half, tap)
                     const size_t frag = (size_t)ct * ksteps + kstep;
                     for (int lane = 0; lane < 64; ++lane) {
-                        const int co = ct * 16 + (lane & 15), q = lane >> 4;
+                        const int co = pn_conv_row_channel(ct, lane & 15, cs.kern == 3 ? 2 : pn_cfg_ct(cs.cfg)), q = lane >> 4;
                         for (int j = 0; j < 8; ++j) {
                             const int ci = map[chunk * 64 + sub * 32 + 8 * q + j];
                             float v = 0.f;
@@ -225,6 +240,15 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     // geometry
     const Buf &ib = n->bufs[cs.in_buf];
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
+    if (cs.kern == 3) {
+        cs.pitch = 32;
+        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
+        if (cs.out_buf >= 0) {
+            const Buf &ob = n->bufs[cs.out_buf];
+            if (ob.H != Ho || ob.W != Wo) return pn_set_error(ctx, PN_ERR_INVALID, "%s: output buffer is %dx%d, conv gives %dx%d", cs.w.c_str(), ob.H, ob.W, Ho, Wo);
+        }
+        return PN_OK;
+    }
     if (cs.cfg == PN_CFG_C64 && ks == 3 && cs.stride == 1 && Wo >= 48 && (long)Ho * Wo >= 2048) cs.cfg = PN_CFG_C64W;   // wide maps: 224-pixel tiles
     const int BP = pn_cfg_pixels(cs.cfg);
     // a block owns R full rows when they fit its pixel tile, else one row cut into equal segments
@@ -271,7 +295,8 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         const ConvSpec &a = n->convs[ids[i]];
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
-            if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.cfg == a.cfg && b.R == a.R && b.Wt == a.Wt) {
+            if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
+                (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf) : b.cfg == a.cfg)) {
                 st.conv_ids.push_back(ids[j]);
                 used[j] = true;
             }
@@ -469,7 +494,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
     for (auto &st : n->steps) {
         if (st.type != Step::CONV) continue;
         const ConvSpec &c0 = n->convs[st.conv_ids[0]];
-        const int BC = pn_cfg_couts(c0.cfg);
+        const int BC = c0.kern == 3 ? c0.wc * 32 : pn_cfg_couts(c0.cfg);
         st.host_probs.clear();
         int max_blocks = 0;
         bool two_bufs = false;
@@ -503,6 +528,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
             P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
             P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
+            P.in_zero_off = (unsigned)((size_t)n->max_batch * ib.H * ib.W * ib.C * es);      // zero page behind every activation buffer
             if (P.lds_two) two_bufs = true;
             max_blocks = std::max(max_blocks, P.nblocks);
             st.host_probs.push_back(P);
@@ -512,10 +538,8 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.nprob = (int)st.host_probs.size();
         st.launch.max_blocks = max_blocks;
         st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R) * (two_bufs ? 2 : 1);
-        {   // the epilogue transposes the f32 output tile through the same LDS allocation
-            const size_t bp = pn_cfg_pixels(c0.cfg);
-            st.launch.lds_bytes = std::max(st.launch.lds_bytes, bp * ((size_t)BC * 4 + 16));
-        }
+        st.launch.kern = c0.kern; st.launch.wc = c0.wc; st.launch.wp = c0.wp; st.launch.nbuf = c0.nbuf;
+        if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf);
         st.launch.probs_dev = st.dev_probs;
         PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),
                                             hipMemcpyHostToDevice, stream));
@@ -616,7 +640,7 @@ int pn_net_finalize(pn_net *n, int precision, int max_batch, int in_h, int in_w)
     int rc = n->kind == PN_NET_RTPOSE_LIGHT3D ? build_rtpose(n) : build_yolo(n);
     if (rc) return rc;
     for (auto &b : n->bufs) {
-        size_t bytes = (size_t)max_batch * b.H * b.W * b.C * n->esize();
+        size_t bytes = (size_t)max_batch * b.H * b.W * b.C * n->esize() + 256;   // + zero page (halo padding source of conv3_kernel)
         if (int r = dev_alloc(n, &b.p, bytes, true)) return r;   // zero: pad channels must read as 0
     }
     for (auto &st : n->steps)

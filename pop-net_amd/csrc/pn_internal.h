@@ -63,6 +63,7 @@ struct ConvProblem {
     int ksteps;            // cin_chunks * KS*KS * 2   (k32 steps per cout tile in wpack)
     int lds_buf_bytes;     // bytes of one LDS halo image
     int lds_two;           // 1: a second image follows (double-buffered chunks), 0: single image
+    unsigned in_zero_off;  // conv3_kernel: byte offset from `in` to >= 16 zero bytes (padding source of the halo DMA)
 };
 
 // Tile configuration ids (see conv_mfma.hip).
@@ -74,6 +75,15 @@ enum pn_conv_cfg {
     PN_CFG_C64W = 4   // 2x2 waves, 2 cout tiles x 7 pixel tiles per wave:  64 couts x 224 px (wide maps)
 };
 int pn_cfg_couts(int cfg);
+// cout tiles per wave of a configuration (TileCfg<>::CT in conv_mfma_kernel.h)
+inline int pn_cfg_ct(int cfg) { return cfg == PN_CFG_C16 ? 1 : 2; }
+// Output channel computed by row `row` (0..15) of packed cout tile `tile`.  The CT tiles a wave owns
+// form a group of 16*CT channels; lane quarter q = row >> 2 of every tile in the group holds channels
+// [4*CT*q, 4*CT*(q+1)) of it, so a lane's CT accumulators are 4*CT consecutive channels (one 16-B
+// bf16 store for CT = 2).  CT = 1 is the natural order.
+inline int pn_conv_row_channel(int tile, int row, int CT) {
+    return (tile / CT) * CT * 16 + 4 * CT * (row >> 2) + 4 * (tile % CT) + (row & 3);
+}
 int pn_cfg_pixels(int cfg);
 
 struct ConvLaunch {
@@ -82,12 +92,15 @@ struct ConvLaunch {
     int stride;    // 1 or 2
     int pitch;     // LDS halo row pitch in pixels (multiple of 8, >= halo columns)
     int cfg;       // pn_conv_cfg
+    int kern = 0, wc = 0, wp = 0, nbuf = 0;   // kern 3: conv3_kernel<ks, wc, wp, nbuf>
     int nprob;
     int max_blocks;          // max nblocks over the group
     size_t lds_bytes;
     const ConvProblem *probs_dev;
 };
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
+int pn_launch_conv3(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);     // conv3_inst_*.hip
+size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
 int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 0 = no limit (direct staging)
 
