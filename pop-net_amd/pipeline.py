@@ -24,7 +24,9 @@ from .utils.paf_to_pose import make_parse_cfg
 
 class PoseEngine:
     def __init__(self, precision="bf16", state_dict=None, device=None, max_batch=32, input_size=224,
-                 w_org=480, h_org=640, intrinsics=INTRINSICS, weight_seed=0):
+                 w_org=480, h_org=640, intrinsics=INTRINSICS, weight_seed=0, private_ctx=False):
+        """private_ctx: give this engine its own pn_ctx (parse workspace), so that several engines can
+        run concurrently on different HIP streams (bench.py pipelines consecutive batches that way)."""
         if not torch.cuda.is_available():
             raise _lib.PopnetError("PoseEngine needs a GPU: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -36,7 +38,7 @@ class PoseEngine:
         else:
             self.model.load_state_dict(state_dict)
         self.model.precision = precision
-        self.ctx = _lib.Context.for_device(self.device.index)
+        self.ctx = _lib.Context(self.device.index) if private_ctx else _lib.Context.for_device(self.device.index)
         self.L = _lib.lib()
         self.net = self.model._compile(self.device, self.max_batch, self.S, self.S)
         self.cfg = make_parse_cfg(default_cfg(), input_size=self.S, w_org=w_org, h_org=h_org, intrinsics=intrinsics,

@@ -419,6 +419,25 @@ def test_engine_bf16_full_batch_runs_and_parse_is_self_consistent(gpu):
             assert np.array_equal(recs[b]["joints_3d"][:assoc.shape[0]], np.array(rec["humans_3d"]))
 
 
+def test_concurrent_engines_on_separate_streams_match_sequential(gpu):
+    """bench.py keeps several batches in flight (one PoseEngine + HIP stream each): the records must not
+    depend on what else is running."""
+    from popnet_amd.pipeline import PoseEngine
+    engs = [PoseEngine(precision="bf16", device=gpu, max_batch=8, private_ctx=True) for _ in range(3)]
+    depths = [torch.from_numpy(synth.synth_depth(8, 640, 480, seed=40 + i)).to(gpu) for i in range(3)]
+    ref = [e.predict(d).clone() for e, d in zip(engs, depths)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(3)]
+    outs = [None] * 3
+    for rep in range(4):
+        for i in range(3):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = engs[i].predict(depths[i]).clone()
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs[i], ref[i])
+
+
 def test_hipgraph_replay_equals_eager(gpu):
     """bench.py replays one captured hipGraph per step: the replayed step must reproduce the eager
     maps and records exactly, for inputs different from the ones seen at capture time."""
