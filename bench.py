@@ -26,7 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 32
+BATCH = int(os.environ.get("POPNET_BENCH_BATCH", "32"))     # 32 = BASELINE configs[1]; the override is for experiments only
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 

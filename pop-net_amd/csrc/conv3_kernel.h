@@ -151,11 +151,17 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
     PN_STAMP_AT(2);
 
     static_assert(NBUF == 1 || NGW <= NSTEP, "the next chunk's DMA is spread one instruction per k-step");
+    // a wave whose 32 couts lie beyond the layer's cout (a 64-cout conv sharing the launch of a 128-cout
+    // sibling, net.hip::harmonize_level) only takes part in the halo DMA and the barriers
+    const bool active = (cb * WC + wc) * (CT * 16) < P.cout;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = NBUF == 2 ? (chunk & 1) * IMG : 0;
         const int nxt = NBUF == 2 ? IMG - cur : 0;
         const bool more = chunk + 1 < nchunks;
         const char *sm = smem + cur;
+        if (!active) {
+            if (NBUF == 2 && more) stage(chunk + 1, nxt);
+        } else {
         // item j = (k-step s = half * KK + tap, pixel tile pt)
 #define PN3_OFF(j) ((((j) / PT) / KK) * 4 * PS + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 16)
         Frag bq[DB];
@@ -185,11 +191,13 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
             __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
         }
 #undef PN3_OFF
+        }
         PN_STAMP_AT(3 + 2 * (chunk & 3));
         if (more) {
             if (NBUF == 2) {
                 // every DMA is older than the 2*(NA-1) weight loads in flight: wait for exactly those
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA - 1)) : "memory");
+                if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA - 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();                         // image c+1 complete, image c free for chunk c+2
             } else {
                 __syncthreads();                         // every wave is done reading this chunk's image

@@ -47,6 +47,7 @@ struct ConvSpec {
     // derived
     int cfg = 0, pitch = 0, R = 0, Wt = 0, cin_chunks = 0;
     int kern = 0, wc = 0, wp = 0, nbuf = 0;   // kern 3: conv3_kernel<ks, wc, wp, nbuf> (bf16, stride 1, strip tiles)
+    int wc_min = 0, nbuf_min = 0;             // set by harmonize_level: share the launch of a wider sibling conv
     void *wpack = nullptr;
     float *bias = nullptr;
     double flops = 0;
@@ -193,11 +194,11 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
         const int segs = (ib0.W + 29) / 30, wt = (ib0.W + segs - 1) / segs;
         if (n->prec == PN_PREC_BF16 && cs.stride == 1 && (ks == 3 || ks == 1) && wt >= 24 && cout > 32 && !getenv("POPNET_NO_CONV3")) {
             cs.kern = 3;
-            cs.wc = cout > 64 ? 4 : (cout > 32 ? 2 : 1);
+            cs.wc = std::max(cout > 64 ? 4 : (cout > 32 ? 2 : 1), cs.wc_min);
             const long tiles112 = (long)n->max_batch * ((ib0.H + 3) / 4) * segs;           // 4-row strip tiles
             cs.wp = (cs.wc == 2 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;           // big maps: 8-row tiles, 256 threads
             const int hr = 4 * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
-            cs.nbuf = (cs.cin_chunks > 1 && ks == 3 && ngw <= 18) ? 2 : 1;
+            cs.nbuf = ((cs.cin_chunks > 1 || cs.nbuf_min == 2) && ks == 3 && ngw <= 18) ? 2 : 1;
             cs.Wt = wt;
             cs.R = std::min(ib0.H, 4 * cs.wp);
         }
@@ -283,6 +284,30 @@ int add_conv(pn_net *n, const std::string &w, const std::string &bn, int ks, int
     cs.cin_map = std::move(cin_map);
     n->convs.push_back(cs);
     return (int)n->convs.size() - 1;
+}
+
+// Independent convs of one level that could share a launch but for their block shape: a 33..64-cout conv next
+// to a wider sibling of the same kernel size takes the sibling's 128-cout block (its two surplus waves only
+// help with the halo DMA, conv3_kernel.h) and the double-buffered variant -- one launch instead of two.
+void harmonize_level(pn_net *n, const std::vector<int> &ids) {
+    for (int ks : {1, 3}) {
+        bool wide = false, multi = false;
+        for (int id : ids) {
+            const ConvSpec &c = n->convs[id];
+            const HostTensor *w = find_t(n, c.w + ".weight");
+            if (!w || w->shape.size() != 4 || c.ks != ks || c.stride != 1) continue;
+            if (w->shape[0] > 64) wide = true;
+            if (w->shape[1] > 64) multi = true;
+        }
+        if (!wide) continue;
+        for (int id : ids) {
+            ConvSpec &c = n->convs[id];
+            const HostTensor *w = find_t(n, c.w + ".weight");
+            if (!w || w->shape.size() != 4 || c.ks != ks || c.stride != 1 || w->shape[0] <= 32) continue;
+            c.wc_min = 4;
+            if (multi) c.nbuf_min = 2;
+        }
+    }
 }
 
 void add_conv_level(pn_net *n, const std::vector<int> &ids) {
@@ -426,6 +451,8 @@ int build_rtpose(pn_net *n) {
                add_conv(n, nm(p3, 12), "", 3, 1, BDb, 0, last ? -1 : CAT, off_z, PN_ACT_SIG_PM2, -1, last ? 2 : -1)});
     }
 
+    for (auto &lv : levels)
+        if (lv[0] != -1) harmonize_level(n, lv);
     for (auto &cs : n->convs)
         if (int rc = prepare_conv(n, cs)) return rc;
     for (auto &cs : n->convs) n->flops_per_frame += cs.flops;
