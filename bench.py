@@ -183,6 +183,16 @@ def main():
     engine.ctx.check(L.pn_net_profile_end(engine.net, C.byref(conv_ms), C.byref(conv_n), C.byref(conv_flops),
                                           C.byref(other_ms), C.byref(other_n)), "pn_net_profile_end")
     graphs, PIPE = graphs_saved, PIPE_saved
+    kernels = []                                                # per instantiation, dominant first
+    for r in range(16):
+        name = C.create_string_buffer(96)
+        kms, kfl, kn = C.c_double(), C.c_double(), C.c_int64()
+        if L.pn_net_profile_kernel(engine.net, r, name, 96, C.byref(kms), C.byref(kn), C.byref(kfl)) != 0:
+            break
+        kernels.append({"kernel": name.value.decode(), "launches_per_step": kn.value / K, "us_per_step": round(kms.value * 1e3 / K, 2),
+                        "avg_launch_us": round(kms.value * 1e3 / max(kn.value, 1), 3),
+                        "tflops": round(kfl.value / (kms.value * 1e-3) / 1e12, 2) if kms.value > 0 else 0.0,
+                        "flops_per_launch": round(kfl.value / max(kn.value, 1), 1)})
 
     if rank == 0:
         recs = frames_host.numpy().view(_lib.POSE_FRAME_DTYPE).reshape(K, BATCH)
@@ -190,11 +200,13 @@ def main():
         same = bool(all(np.array_equal(raw[0], raw[k]) for k in range(1, K)))     # same input every step -> same records from every engine
         total_frames = world * K * BATCH
         achieved = conv_flops.value / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
-        traffic = None
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+        dom = kernels[0] if kernels else {"kernel": "none", "us_per_step": 0.0, "avg_launch_us": 0.0, "tflops": 0.0, "flops_per_launch": 0.0, "launches_per_step": 0}
+        traffic = None                                          # HBM bytes per launch of the dominant kernel (separate rocprofv3 --pmc passes)
         pmc = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("by_kernel", {}).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -207,16 +219,14 @@ def main():
                        "frames_per_step_per_gpu": BATCH, "input": "480x640 f16", "network_input": "224x224",
                        "weights": "seeded random, heat head calibrated (pipeline.calibrate_heads)",
                        "parallelism": "frames sharded x%d, one all-gather of records" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all %d launches/forward)" % (conv_n.value // max(K, 1)),
-                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
-                         "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4),
-                         "traffic": traffic,
-                         "avg_launch_us": round(conv_ms.value * 1e3 / max(conv_n.value, 1), 3),
-                         "flops_per_launch": round(conv_flops.value / max(conv_n.value, 1), 1),
-                         "conv_stack_tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
-                         "conv_ms_per_step": round(conv_ms.value / K, 4), "stem_pool_ms_per_step": round(other_ms.value / K, 4),
-                         "measured": "HIP events around every conv launch, same %d steps re-run eagerly right after the timed region (%.4f ms/step with events)" % (K, elapsed_profiled / K * 1e3)},
+            "roofline": {"bound": "mfma", "kernel": dom["kernel"] + " (dominant convolution instantiation: %.0f of %.0f conv us/step)" % (dom["us_per_step"], conv_ms.value * 1e3 / K),
+                         "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
+                         "traffic": traffic, "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"],
+                         "launches_per_step": dom["launches_per_step"],
+                         "conv_stack": {"achieved": round(achieved, 2), "frac": round(achieved / peak, 4), "launches_per_step": conv_n.value // max(K, 1),
+                                        "ms_per_step": round(conv_ms.value / K, 4), "tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
+                                        "stem_pool_ms_per_step": round(other_ms.value / K, 4), "by_kernel": kernels},
+                         "measured": "HIP events around every conv launch on the launch stream, the same %d steps re-run eagerly on one engine right after the timed region (%.4f ms/step with events)" % (K, elapsed_profiled / K * 1e3)},
             "frame_stats": {"mean_peaks": round(float(recs['n_peaks'].mean()), 2),
                             "mean_persons": round(float(recs['n_persons'].mean()), 3),
                             "overflow_frames": int((recs['status'] != 0).sum()),

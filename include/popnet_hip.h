@@ -114,6 +114,11 @@ double pn_net_flops_per_frame(pn_net *net);
 int pn_net_profile_begin(pn_net *net);
 int pn_net_profile_end(pn_net *net, double *conv_ms, int64_t *conv_launches, double *conv_flops,
                        double *other_ms, int64_t *other_launches);
+/* After pn_net_profile_end: the convolution kernel instantiation with the rank-th largest summed
+ * duration (rank 0 = the dominant kernel), its launches and the algorithmic FLOPs they covered.
+ * PN_ERR_INVALID when rank is past the last instantiation. */
+int pn_net_profile_kernel(pn_net *net, int rank, char *name, size_t name_cap, double *ms,
+                          int64_t *launches, double *flops);
 
 /* ---- Open-Pose+ parsing ---------------------------------------------------------------------
  * Replaces, per frame, paf_to_pose + paf_to_human_list + the depth read-out / rescale /

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "pn_net_flops_per_frame": (_d, [_vp]),
     "pn_net_profile_begin": (_i, [_vp]),
     "pn_net_profile_end": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_int64), C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_int64)]),
+    "pn_net_profile_kernel": (_i, [_vp, _i, C.c_char_p, _sz, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pn_parse_cfg_default": (None, [C.POINTER(ParseCfg)]),
     "pn_parse_paf": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),

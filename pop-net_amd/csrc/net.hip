@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -96,7 +97,8 @@ struct pn_net {
     int out_h = 0, out_w = 0;
     // optional per-launch HIP-event timing (bench.py's live roofline measurement)
     bool profiling = false;
-    struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+    struct ProfRec { hipEvent_t a, b; int kind; double flops; std::string label; };
+    std::map<std::string, std::pair<std::pair<double, int64_t>, double>> prof_by_kernel;   // label -> ((ms, launches), flops), filled by profile_end
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
 
@@ -198,7 +200,9 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
             const long tiles112 = (long)n->max_batch * ((ib0.H + 3) / 4) * segs;           // 4-row strip tiles
             cs.wp = (cs.wc == 2 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;           // big maps: 8-row tiles, 256 threads
             const int hr = 4 * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
-            cs.nbuf = ((cs.cin_chunks > 1 || cs.nbuf_min == 2) && ks == 3 && ngw <= 18) ? 2 : 1;
+            // single halo image (4 waves / SIMD) beats the double-buffered variant (3 waves / SIMD) on every level
+            // of both networks (profiles/README.md, r01 v8); POPNET_CONV3_NBUF2=1 selects the latter for experiments
+            cs.nbuf = ((cs.cin_chunks > 1 || cs.nbuf_min == 2) && ks == 3 && ngw <= 18 && getenv("POPNET_CONV3_NBUF2")) ? 2 : 1;
             cs.Wt = wt;
             cs.R = std::min(ib0.H, 4 * cs.wp);
         }
@@ -597,8 +601,15 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
             pr = &n->prof[n->prof_used++];
             pr->kind = (int)st.type;
             pr->flops = 0;
-            if (st.type == Step::CONV)
+            pr->label.clear();
+            if (st.type == Step::CONV) {
                 for (int id : st.conv_ids) pr->flops += n->convs[id].flops * B;
+                char lb[96];
+                const ConvLaunch &cl = st.launch;
+                if (cl.kern == 3) snprintf(lb, sizeof lb, "conv3_kernel<%d, %d, %d, %d>", cl.ks, cl.wc, cl.wp, cl.nbuf);
+                else snprintf(lb, sizeof lb, "conv_mfma_kernel<%d, %d, %d, %d, %d>", cl.prec, cl.ks, cl.stride, cl.pitch, cl.cfg);
+                pr->label = lb;
+            }
             PN_HIP_CHECK(ctx, hipEventRecord(pr->a, stream));
         }
         if (st.type == Step::STEM) {
@@ -729,6 +740,7 @@ int pn_net_read_activation(pn_net *n, const char *name, int B, float *host_out, 
 double pn_net_flops_per_frame(pn_net *n) { return n ? n->flops_per_frame : 0.0; }
 
 int pn_net_profile_begin(pn_net *n) {
+    if (n) n->prof_by_kernel.clear();
     if (!n) return PN_ERR_INVALID;
     n->profiling = true;
     n->prof_used = 0;
@@ -746,8 +758,11 @@ int pn_net_profile_end(pn_net *n, double *conv_ms, int64_t *conv_launches, doubl
         PN_HIP_CHECK(ctx, hipEventSynchronize(n->prof[i].b));
         float ms = 0.f;
         PN_HIP_CHECK(ctx, hipEventElapsedTime(&ms, n->prof[i].a, n->prof[i].b));
-        if (n->prof[i].kind == (int)Step::CONV) { cm += ms; cf += n->prof[i].flops; ++cl; }
-        else { om += ms; ++ol; }
+        if (n->prof[i].kind == (int)Step::CONV) {
+            cm += ms; cf += n->prof[i].flops; ++cl;
+            auto &e = n->prof_by_kernel[n->prof[i].label];
+            e.first.first += ms; e.first.second += 1; e.second += n->prof[i].flops;
+        } else { om += ms; ++ol; }
     }
     n->prof_used = 0;
     if (conv_ms) *conv_ms = cm;
@@ -755,6 +770,20 @@ int pn_net_profile_end(pn_net *n, double *conv_ms, int64_t *conv_launches, doubl
     if (conv_flops) *conv_flops = cf;
     if (other_ms) *other_ms = om;
     if (other_launches) *other_launches = ol;
+    return PN_OK;
+}
+
+int pn_net_profile_kernel(pn_net *n, int rank, char *name, size_t name_cap, double *ms, int64_t *launches, double *flops) {
+    if (!n || rank < 0) return PN_ERR_INVALID;
+    std::vector<std::pair<double, std::string>> order;
+    for (auto &kv : n->prof_by_kernel) order.push_back({-kv.second.first.first, kv.first});
+    std::sort(order.begin(), order.end());
+    if ((size_t)rank >= order.size()) return PN_ERR_INVALID;
+    const auto &e = n->prof_by_kernel[order[rank].second];
+    if (name && name_cap) { strncpy(name, order[rank].second.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (ms) *ms = e.first.first;
+    if (launches) *launches = e.first.second;
+    if (flops) *flops = e.second;
     return PN_OK;
 }
 
