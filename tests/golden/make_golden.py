@@ -452,13 +452,80 @@ def golden_script_yolo():
     print("F7 yolo script: persons per frame", [len(f) for f in keep["human_pred_set_2d"]])
 
 
+# ---- F8: metric known-answers from the reference's util/eval_pck.py and util/eval_mAP.py -----------
+def metric_case(seed, n_img=14):
+    """Seeded prediction / ground-truth sets in the result-schema shapes: 0-3 GT persons per image, predictions =
+    jittered GT (some joints missing = [-1,-1], conf 0), dropped persons, extra false positives, tied confidences,
+    images without predictions.  Every image keeps >= 1 GT person (the reference's mAP code needs one)."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 504.1189880371094, 504.042724609375, 231.7421875, 320.62640380859375
+    p2, p3, pc, g2, g3 = [], [], [], [], []
+    for i in range(n_img):
+        ng = int(rng.integers(1, 4))
+        G2, G3, P2, P3, PC = [], [], [], [], []
+        for g in range(ng):
+            base = rng.uniform([60, 80], [420, 560])
+            j2 = base + rng.uniform(-60, 60, (15, 2)) * [0.6, 1.6]
+            z = rng.uniform(1.5, 4.5) + rng.normal(0, 0.05, 15)
+            j3 = np.c_[(j2[:, 0] - cx) / fx * z, (j2[:, 1] - cy) / fy * z, z]
+            G2.append(j2.tolist()); G3.append(j3.tolist())
+            if rng.random() < 0.8:                       # detected
+                noise = rng.choice([1.0, 6.0, 25.0])
+                q2 = j2 + rng.normal(0, noise, (15, 2))
+                qz = z + rng.normal(0, rng.choice([0.01, 0.06, 0.2]), 15)
+                q3 = np.c_[(q2[:, 0] - cx) / fx * qz, (q2[:, 1] - cy) / fy * qz, qz]
+                conf = np.round(rng.uniform(0.2, 1.0, 15), 1)          # coarse: many exact ties
+                miss = rng.random(15) < 0.12
+                q2[miss] = -1; q3[miss] = -1; conf[miss] = 0
+                P2.append(q2.tolist()); P3.append(q3.tolist()); PC.append(conf.tolist())
+        for _ in range(int(rng.integers(0, 2))):        # false positive somewhere else
+            q2 = rng.uniform([0, 0], [480, 640], (15, 2)); qz = rng.uniform(1, 5, 15)
+            P2.append(q2.tolist()); P3.append(np.c_[(q2[:, 0] - cx) / fx * qz, (q2[:, 1] - cy) / fy * qz, qz].tolist())
+            PC.append(np.round(rng.uniform(0.1, 0.6, 15), 1).tolist())
+        if i % 6 == 5:
+            P2, P3, PC = [], [], []                      # image without predictions
+        order = rng.permutation(len(P2))
+        p2.append([P2[k] for k in order]); p3.append([P3[k] for k in order]); pc.append([PC[k] for k in order])
+        g2.append(G2); g3.append(G3)
+    return p2, p3, pc, g2, g3
+
+
+def golden_metrics():
+    sys.path.insert(0, REF)
+    import copy
+    import io
+    import contextlib
+    from util import eval_pck as RP, eval_mAP as RA, util_functions as RU
+    names = RU.get_keypoints()
+    out = {"cases": []}
+    for seed in (101, 102, 103):
+        p2, p3, pc, g2, g3 = metric_case(seed)
+        with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+            d2, k2 = RP.eval_human_dataset_2d_PCKh(copy.deepcopy(p2), copy.deepcopy(g2), num_joints=15, head_id=0, neck_id=1, iou_th=0.5)
+            d3, k3 = RP.eval_human_dataset_3d(copy.deepcopy(p2), copy.deepcopy(g2), copy.deepcopy(p3), copy.deepcopy(g3), num_joints=15, dist_th=0.1, iou_th=0.5)
+            a2 = RA.eval_ap_mpii_v2(copy.deepcopy(p2), copy.deepcopy(pc), copy.deepcopy(g2), gt_visibility_set=[], head_id=0, neck_id=1, joint_names=names, thresh=0.5)
+            a3 = RA.eval_ap_3D(copy.deepcopy(p3), copy.deepcopy(pc), copy.deepcopy(g3), gt_visibility_set=[], joint_names=names, thresh=0.1)
+            md = [np.asarray(x).tolist() for x in RP.match_humans_3d(p2[0], g2[0], p3[0], g3[0], 0.5)]
+        out["cases"].append({"seed": seed, "pck2d": [float(v) for v in k2], "err2d": [float(v) for v in d2],
+                             "pck3d": [float(v) for v in k3], "err3d": [float(v) for v in d3],
+                             "ap2d": np.asarray(a2).tolist(), "ap3d": np.asarray(a3).tolist(), "match3d_img0": md})
+        print("F8 seed %d: PCK2D %.3f PCK3D %.3f AP2D %.2f AP3D %.2f" % (seed, np.mean(k2), np.mean(k3), a2[-1], a3[-1]))
+    # perfect predictions: AP 100 / PCK 1 (SURVEY F5)
+    p2, p3, pc, g2, g3 = metric_case(104)
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+        a2 = RA.eval_ap_mpii_v2(copy.deepcopy(g2), [], copy.deepcopy(g2), gt_visibility_set=[], head_id=0, neck_id=1, joint_names=names, thresh=0.5)
+        d2, k2 = RP.eval_human_dataset_2d_PCKh(copy.deepcopy(g2), copy.deepcopy(g2), num_joints=15, head_id=0, neck_id=1, iou_th=0.5)
+    out["perfect"] = {"seed": 104, "ap2d": np.asarray(a2).tolist(), "pck2d": [float(v) for v in k2]}
+    json.dump(out, open(os.path.join(HERE, "metrics.json"), "w"))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate golden vectors"
     install_shims()
     import popnet_amd  # noqa: F401
-    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo"]
+    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics"]
     fns = {"keys": golden_state_dicts, "forward": golden_forward, "parse": golden_parse, "yolo": golden_yolo,
            "pafprocess": golden_pafprocess, "script": golden_script,
-           "script_yolo": golden_script_yolo}
+           "script_yolo": golden_script_yolo, "metrics": golden_metrics}
     for w in which:
         fns[w]()
