@@ -7,6 +7,7 @@ Bit-exact for every index / integer / byte result and for all float results of t
 (different summation order), bf16 forward within the tolerance stated in each test.
 `/root/reference` is never touched here."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -18,6 +19,7 @@ from popnet_amd import _lib, synth
 from popnet_amd.config import default_cfg
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _loaded_native():
@@ -481,3 +483,51 @@ def test_hipgraph_replay_equals_eager(gpu):
             h, p, z, recs = snapshot()
             assert torch.equal(h, eager[name][0]) and torch.equal(p, eager[name][1]) and torch.equal(z, eager[name][2])
             assert recs == eager[name][3]
+
+
+# ---------------------------------------------------------------------------------------------
+# the evaluation-script drop-in: labels.json + .npy frames in, eval_data.json + metrics out
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", ["rtpose", "yolo"])
+def test_evaluate_mpreal_script_matches_reference_scripts(gpu, golden, tmp_path, net):
+    """scripts/evaluate_mpreal.py on the same fake two-frame dataset and checkpoint the golden generator fed to
+    the reference's evaluation scripts: eval_data.json must match theirs (assignment exact, 3D within 1e-3 m)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("evaluate_mpreal", os.path.join(ROOT, "scripts", "evaluate_mpreal.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    s = golden.script if net == "rtpose" else golden.script_yolo
+    key = "rtpose_light3d" if net == "rtpose" else "yolo_posenet"
+    sd = state_dict_from_keys(golden.keys[key], seed=s["weight_seed"])
+    if net == "rtpose":
+        sd["model2_2.12.bias"][:15] += torch.tensor(s["heat_bias_shift"])
+    else:
+        sd["model2_4.0.weight"][[4, 54]] -= np.float32(s["conf_weight_shift"])
+    torch.save({"module." + k: v for k, v in sd.items()}, tmp_path / "ckpt.pth")
+    img_dir = tmp_path / "depth_maps"
+    img_dir.mkdir()
+    frames = synth.synth_depth(2, 640, 480, seed=s["depth_seed"])
+    labels = {"intrinsics": {"fx": 504.1189880371094, "fy": 504.042724609375, "cx": 231.7421875, "cy": 320.62640380859375}}
+    rng = np.random.default_rng(5)
+    for i in range(2):
+        np.save(img_dir / ("f%d.npy" % i), frames[i])
+        j2 = rng.uniform(50, 400, (15, 2))
+        labels["f%d.npy" % i] = [{"2d_joints": j2.tolist(), "3d_joints": np.c_[j2 / 200, np.full(15, 3.0)].tolist()}]
+    json.dump(labels, open(tmp_path / "labels.json", "w"))
+    out = mod.main(["--annotations", str(tmp_path / "labels.json"), "--image-dir", str(img_dir), "--w-org", "480", "--h-org", "640",
+                    "--batch-size", "2", "--weight", str(tmp_path / "ckpt.pth"), "--output-dir", str(tmp_path / "out"), "--net", net])
+    data = json.load(open(tmp_path / "out" / "eval_data.json"))
+    assert len(data["human_pred_set_2d"]) == 2 and data["human_gt_set_2d"][0] == [labels["f0.npy"][0]["2d_joints"]]
+    for b in range(2):
+        want2, want3 = np.array(s["human_pred_set_2d"][b]), np.array(s["human_pred_set_3d"][b])
+        got2, got3 = np.array(data["human_pred_set_2d"][b]), np.array(data["human_pred_set_3d"][b])
+        assert got2.shape == want2.shape and got3.shape == want3.shape
+        if got2.size:
+            assert np.abs(got2 - want2).max() < (1e-9 if net == "rtpose" else 5e-2)
+            assert np.abs(got3 - want3).max() < 1e-3
+            assert np.abs(np.array(data["human_pred_set_part_conf"][b]) - np.array(s["human_pred_set_part_conf"][b])).max() < 1e-4
+        if net == "rtpose":
+            assert data["human_pred_set_visibility"][b] == s["human_pred_set_visibility"][b]
+    assert out is not None and len(out["ap2d"]) == 16 and len(out["pck3d"]) == 15

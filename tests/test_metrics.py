@@ -74,3 +74,46 @@ def test_cli_round_trip(tmp_path):
     json.dump(res, open(tmp_path / "results.json", "w"))
     out = M.evaluate_mp_human_3d(str(tmp_path / "labels.json"), str(tmp_path / "results.json"), verbose=False)
     assert close(out["ap2d"], GOLD["cases"][0]["ap2d"], 1e-9) and close(out["pck3d"], GOLD["cases"][0]["pck3d"])
+
+
+# ---------------------------------------------------------------------------------------------
+# dataset ingest / result schema (host logic, no GPU)
+# ---------------------------------------------------------------------------------------------
+def test_dataset_listing_dtype_and_batching(tmp_path):
+    from popnet_amd import dataset, _lib
+    labels = {"b.npy": [{"2d_joints": [[1, 2]] * 15, "3d_joints": [[1, 2, 3]] * 15}], "intrinsics": {"fx": 2, "fy": 3, "cx": 4, "cy": 5},
+              "a.npy": [], "c.npy": []}
+    json.dump(labels, open(tmp_path / "labels.json", "w"))
+    np.save(tmp_path / "b.npy", np.full((6, 4), 1.5, np.float16))
+    np.save(tmp_path / "a.npy", np.full((6, 4), 2.5, np.float16))
+    np.save(tmp_path / "c.npy", np.full((6, 4), 3.5, np.float64))
+    fr = dataset.MP3DHPFrames(str(tmp_path), str(tmp_path / "labels.json"))
+    assert fr.ids == ["b.npy", "a.npy", "c.npy"] and len(fr) == 3            # dict order, 'intrinsics' skipped
+    assert fr.intrinsics == {"fx": 2, "fy": 3, "cx": 4, "cy": 5}
+    assert fr.load(0).dtype == np.float16 and fr.load(2).dtype == np.float32   # float64 narrowed like Cvt2ndarray
+    got = list(fr.batches([0, 1], 2))
+    assert got[0][0] == [0, 1] and got[0][1].shape == (2, 6, 4)
+    assert len(list(fr.batches([0, 1], 2, drop_last=True))) == 1 and len(list(fr.batches([0], 2, drop_last=True))) == 0
+    with pytest.raises(_lib.PopnetError):
+        list(fr.batches([1, 2], 2))                                            # mixed dtypes in one batch
+    g2, g3 = fr.ground_truth()
+    assert len(g2) == 3 and g2[0][0][0] == [1, 2] and g3[1] == []
+
+
+def test_pose_records_to_result_schema():
+    from popnet_amd import dataset, _lib
+    recs = np.zeros(2, dtype=_lib.POSE_FRAME_DTYPE)
+    recs[0]["n_persons"] = 2
+    recs[0]["person_joint"][:2] = -1
+    recs[0]["person_joint"][0, :3] = [4, 5, 6]
+    recs[0]["joints_2d"][0, 0] = [10.5, 20.25]
+    recs[0]["joints_3d"][0, 0] = [0.1, 0.2, 3.0]
+    recs[0]["part_conf"][0, 0] = 0.75
+    d = dataset.pose_records_to_lists(recs)
+    assert len(d["human_pred_set_2d"]) == 2 and len(d["human_pred_set_2d"][0]) == 2 and d["human_pred_set_2d"][1] == []
+    assert d["human_pred_set_2d"][0][0][0] == [10.5, 20.25] and d["human_pred_set_3d"][0][0][0] == [0.1, 0.2, 3.0]
+    assert d["human_pred_set_visibility"][0][0][:4] == [1, 1, 1, 0] and d["human_pred_set_part_conf"][0][0][0] == 0.75
+    json.dumps(d)                                                              # plain lists / floats only
+    recs[1]["status"] = 1
+    with pytest.raises(_lib.PopnetError):
+        dataset.pose_records_to_lists(recs)
