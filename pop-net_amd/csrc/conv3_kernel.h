@@ -118,6 +118,9 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
         const int iy = iy0 + 2 * i + hrow;
         const bool inb = (int)on & (int)col_ok & (int)((unsigned)iy < (unsigned)Hin);
         unsigned off = (unsigned)(iy * row_b + pc * 16) + coloff;
+#ifdef PN_CONV3_FAKE_LINDMA   // timing experiment (wrong results): each DMA instruction reads 1 KB of consecutive bytes
+        off = (unsigned)(min(max(iy0 + 2 * i, 0), Hin - 2) * row_b + max(ix0, 0) * col_b) + lane * 16;
+#endif
         asm volatile("" : "+v"(off));                    // materialise: the select below must stay a v_cndmask, not a branch
         const unsigned zrel = zero_rel - (unsigned)(chunk * 128);
         pn_glds16(img + chunk * 128 + (inb ? off : zrel),
@@ -138,6 +141,9 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
         int ry = (int)(((float)s + 0.5f) * inv_wc);
         int rx = s - ry * Wc;
         baddr[pt] = q * PS + (ry * PITCH + rx) * 16;
+#ifdef PN_CONV3_FAKE_NOWRAP   // timing experiment only (wrong results): every pixel tile reads 16 consecutive entries
+        baddr[pt] = q * PS + (pt * 16 + c) * 16;
+#endif
     }
     f32x4 acc[CT][PT];
 #pragma unroll
@@ -174,8 +180,12 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
             if (pt == 0) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {        // wpack ends with NA-1 spare fragments
+#ifndef PN_CONV3_FAKE_NOA                                // timing experiments only (wrong results)
                     aq[(s + NA - 1) % NA][ct] = load_a_frag2<PN_PREC_BF16>(wbase[ct], wlane);
+#endif
+#ifndef PN_CONV3_FAKE_SAMEA                              // timing experiment: every weight load hits the same (L1-resident) KB
                     wbase[ct] += FRAGB;
+#endif
                 }
                 // double-buffered: the next chunk's image is fetched by ONE DMA instruction per k-step (the
                 // compiler does not count asm memory ops, so each one shortens the effective depth of the
@@ -183,7 +193,9 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
                 if (NBUF == 2 && s < NGW) stage_one(chunk + 1, s, nxt, more);
             }
             const int jr = j + DB - 1;
+#ifndef PN_CONV3_FAKE_NOB
             if (jr < NITEM) bq[jr % DB] = read_b_frag<PN_PREC_BF16>(sm + PN3_OFF(jr), baddr[jr % PT]);
+#endif
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) acc[ct][pt] = mma(aq[s % NA][ct], bq[j % DB], acc[ct][pt]);
             if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);

@@ -9,10 +9,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <string>
 #include <vector>
 #ifdef PN_STAMP
 __device__ unsigned long long *g_stamps;
-#define PN_STAMP_AT(i) do { if (threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PN_STAMP_AT(i) do { if (threadIdx.x == 0) { size_t b_ = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16; g_stamps[b_ + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0) g_stamps[b_ + 14] = __builtin_amdgcn_s_memrealtime(); if ((i) == 12) g_stamps[b_ + 15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define PN_STAMP_AT(i) do {} while (0)
 #endif
@@ -115,7 +117,7 @@ int main(int argc, char **argv) {
 #endif
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double flops = 2.0 * npx * cout * (double)cin * KK;
-    int nblocks = 0;
+    int nblocks = 0, lab_gridx = 0, lab_gridy = 1;
     auto run = [&]() {};
     (void)run;
     if (!strcmp(kname, "old")) {
@@ -179,13 +181,39 @@ int main(int argc, char **argv) {
         P.cin_chunks = chunks; P.in_cs = cin_pad; P.cout = cout; P.out_cs = out_cs; P.res_cs = cout; P.act = act; P.R = R; P.Wt = Wt;
         P.tiles_x = (W + Wt - 1) / Wt; P.tiles_per_img = ((H + R - 1) / R) * P.tiles_x; P.cout_blocks = (cout + BC - 1) / BC;
         P.nblocks = B * P.tiles_per_img * P.cout_blocks; P.ksteps = ksteps;
-        ConvProblem *dP; CK(hipMalloc(&dP, sizeof P)); CK(hipMemcpy(dP, &P, sizeof P, hipMemcpyHostToDevice));
-        nblocks = P.nblocks;
+        // GROUP="cin:cout,cin:cout": further problems (same map, kernel size and block shape) in the same launch, unchecked
+        std::vector<ConvProblem> probs(1, P);
+        if (const char *g = getenv("GROUP")) {
+            std::string gs(g);
+            size_t pos = 0;
+            while (pos < gs.size()) {
+                size_t e = gs.find(',', pos); if (e == std::string::npos) e = gs.size();
+                int ci = 0, co = 0; sscanf(gs.substr(pos, e - pos).c_str(), "%d:%d", &ci, &co);
+                pos = e + 1;
+                const int cp = (ci + 63) / 64 * 64, ch2 = cp / 64, ks2 = ch2 * KK * 2, cop = (co + BC - 1) / BC * BC;
+                std::vector<uint16_t> in2(npx * cp); for (auto &v : in2) v = f2bf((rand() % 2001 - 1000) / 1000.0f);
+                std::vector<uint16_t> w2((size_t)(cop / 16) * ks2 * 512 + 5 * 512); for (auto &v : w2) v = f2bf((rand() % 2001 - 1000) / 20000.0f);
+                __bf16 *di; void *dw2; __bf16 *do2; float *db2;
+                CK(hipMalloc(&di, in2.size() * 2 + 256)); CK(hipMemset(di, 0, in2.size() * 2 + 256)); CK(hipMemcpy(di, in2.data(), in2.size() * 2, hipMemcpyHostToDevice));
+                CK(hipMalloc(&dw2, w2.size() * 2)); CK(hipMemcpy(dw2, w2.data(), w2.size() * 2, hipMemcpyHostToDevice));
+                CK(hipMalloc(&do2, npx * cop * 2)); CK(hipMalloc(&db2, cop * 4)); CK(hipMemset(db2, 0, cop * 4));
+                ConvProblem Q = P;
+                Q.in = di; Q.in_zero_off = (unsigned)(in2.size() * 2); Q.wpack = dw2; Q.bias = db2; Q.res = nullptr; Q.out = do2;
+                Q.cin_chunks = ch2; Q.in_cs = cp; Q.cout = co; Q.out_cs = cop; Q.cout_blocks = cop / BC; Q.nblocks = B * Q.tiles_per_img * Q.cout_blocks; Q.ksteps = ks2;
+                probs.push_back(Q);
+                flops += 2.0 * npx * co * (double)ci * KK;
+            }
+        }
+        int maxb = 0; for (auto &q : probs) maxb = std::max(maxb, q.nblocks);
+        ConvProblem *dP; CK(hipMalloc(&dP, sizeof(P) * probs.size())); CK(hipMemcpy(dP, probs.data(), sizeof(P) * probs.size(), hipMemcpyHostToDevice));
+        nblocks = maxb * (int)probs.size();
+        const int gridx = maxb, gridy = (int)probs.size();
+        lab_gridx = gridx; lab_gridy = gridy;
         const int nbuf = getenv("NBUF") ? atoi(getenv("NBUF")) : 1;
         size_t lds = (size_t)8 * (4 * WP + ks - 1) * 32 * 16 * nbuf + 1024;
         printf("v3 kernel: cfg %d (WC %d WP %d) NBUF %d R %d Wt %d blocks %d lds %zu\n", cfg, WC, WP, nbuf, R, Wt, nblocks, lds);
         auto launch = [&]() {
-            dim3 grid(nblocks, 1);
+            dim3 grid(gridx, gridy);
 #define LAB3(KS_, WC_, WP_, NB_) if (ks == KS_ && WC == WC_ && WP == WP_ && nbuf == NB_) { auto kern = conv3_kernel<KS_, WC_, WP_, NB_>; \
                 if (lds > 48 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL(kern, grid, dim3(WC_ * WP_ * 64), lds, 0, dP); return; }
@@ -217,13 +245,27 @@ int main(int argc, char **argv) {
         std::vector<unsigned long long> st((size_t)nblocks * 16);
         CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull; for (int b = 0; b < nblocks; ++b) if (st[b * 16]) t0 = std::min(t0, st[b * 16]);
-        double avg[16] = {0}; int cnt = 0;
-        for (int b = 0; b < nblocks; ++b) { if (!st[b * 16]) continue; ++cnt; for (int i = 0; i < 16; ++i) avg[i] += st[b * 16 + i] ? (double)(st[b * 16 + i] - st[b * 16]) : 0; }
-        printf("stamps (cycles @100MHz ticks? from block start, avg over %d blocks):", cnt);
-        for (int i = 0; i < 16; ++i) printf(" %.0f", avg[i] / cnt);
+        if (!lab_gridx) lab_gridx = nblocks;
+        for (int y = 0; y < lab_gridy; ++y) {
+            double avg[16] = {0}; int cnt = 0;
+            for (int b = y * lab_gridx; b < (y + 1) * lab_gridx && b < nblocks; ++b) { if (!st[b * 16]) continue; ++cnt; for (int i = 0; i < 14; ++i) avg[i] += st[b * 16 + i] ? (double)(st[b * 16 + i] - st[b * 16]) : 0; }
+            printf("stamps problem %d (shader cycles from block start, avg over %d blocks):", y, cnt);
+            for (int i = 0; i < 13; ++i) printf(" %.0f", cnt ? avg[i] / cnt : 0.0);
+            printf("\n");
+        }
         printf("\n first-block-start spread: ");
         unsigned long long tmax = 0; for (int b = 0; b < nblocks; ++b) tmax = std::max(tmax, st[b * 16] - t0);
         printf("%llu\n", tmax);
+        {   // global timeline from s_memrealtime (100 MHz): when do blocks start and end
+            unsigned long long r0 = ~0ull; for (int b = 0; b < nblocks; ++b) if (st[b * 16 + 14]) r0 = std::min(r0, st[b * 16 + 14]);
+            std::vector<double> starts, ends;
+            for (int b = 0; b < nblocks; ++b) if (st[b * 16 + 14] && st[b * 16 + 15]) { starts.push_back((st[b * 16 + 14] - r0) * 0.01); ends.push_back((st[b * 16 + 15] - r0) * 0.01); }
+            std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+            auto pct = [](std::vector<double> &v, double p) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(p * v.size()))]; };
+            printf(" block starts us: p50 %.1f p90 %.1f max %.1f | ends: p10 %.1f p50 %.1f p90 %.1f max %.1f  (%zu blocks)\n", pct(starts, .5), pct(starts, .9), starts.empty() ? 0 : starts.back(),
+                   pct(ends, .1), pct(ends, .5), pct(ends, .9), ends.empty() ? 0 : ends.back(), starts.size());
+            for (int y = 0; y < nblocks / std::max(1, (int)(nblocks / std::max(1, 1))); ++y) break;
+        }
         for (int b = 0; b < std::min(nblocks, 4); ++b) { printf(" block %d:", b); for (int i = 0; i < 16; ++i) printf(" %lld", st[b*16+i] ? (long long)(st[b * 16 + i] - t0) : -1); printf("\n"); }
     }
 #endif
