@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
+    ap.add_argument("--net", default="rtpose", choices=["rtpose", "yolo"],
+                    help="rtpose = rtpose_light3d + PAF parsing (the headline workload); yolo = YoloPoseNet + box decode (SURVEY 8a rows 7, 12)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight per GPU (engines on separate HIP streams)")
     args = ap.parse_args()
 
@@ -93,19 +95,21 @@ def main():
 
     import popnet_amd  # noqa: F401
     from popnet_amd import _lib, synth
-    from popnet_amd.pipeline import PoseEngine
+    from popnet_amd.pipeline import PoseEngine, YoloEngine
+    Engine = PoseEngine if args.net == "rtpose" else YoloEngine
+    REC = _lib.POSE_FRAME_DTYPE if args.net == "rtpose" else _lib.YOLO_FRAME_DTYPE
 
     # PIPE engines (own activations, parse workspace, record buffers, HIP stream and step graph): batch
     # k runs on engine k % PIPE, so the latency-bound tail of one batch (small head convs, pose parsing,
     # the record D2H copy) overlaps with the convolutions of the next.  Every batch still runs the whole
     # path; only its latency, not the work, is hidden.
     PIPE = max(1, args.pipeline)
-    engines = [PoseEngine(precision=args.precision, device=dev, max_batch=BATCH, private_ctx=PIPE > 1) for _ in range(PIPE)]
+    engines = [Engine(precision=args.precision, device=dev, max_batch=BATCH, private_ctx=PIPE > 1) for _ in range(PIPE)]
     engine = engines[0]
     depth_host = synth.synth_depth(BATCH, 640, 480, seed=1234 + rank)
     depth = torch.from_numpy(depth_host).to(dev)
     K, W = args.steps, args.warmup
-    item = _lib.POSE_FRAME_DTYPE.itemsize
+    item = REC.itemsize
     frames_dev = torch.empty((K, BATCH, item), device=dev, dtype=torch.uint8)
     gathered = torch.empty((world * K * BATCH, item), device=dev, dtype=torch.uint8) if world > 1 else None
 
@@ -205,7 +209,7 @@ def main():
                         "flops_per_launch": round(kfl.value / max(kn.value, 1), 1)})
 
     if rank == 0:
-        recs = frames_host.numpy().view(_lib.POSE_FRAME_DTYPE).reshape(K, BATCH)
+        recs = frames_host.numpy().view(REC).reshape(K, BATCH)
         raw = frames_host.numpy().reshape(K, -1)
         same = bool(all(np.array_equal(raw[0], raw[k]) for k in range(1, K)))     # same input every step -> same records from every engine
         total_frames = world * K * BATCH
@@ -225,9 +229,10 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 4), "launch_mode": ("eager" if args.no_graph else "hipGraph replay (one graph per step)") + ", %d batches in flight on separate HIP streams" % PIPE, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch=32 synthetic 480x640 f16 depth frames per GPU per step, "
-                                   "resize->224^2, rtpose_light3d forward + PAF pose parsing, records D2H",
+                                   "resize->224^2, " + ("rtpose_light3d forward + PAF pose parsing" if args.net == "rtpose" else
+                                                        "YoloPoseNet forward + box decode / NMS / skeleton read-out (secondary network of the path)") + ", records D2H",
                        "frames_per_step_per_gpu": BATCH, "input": "480x640 f16", "network_input": "224x224",
-                       "weights": "seeded random, heat head calibrated (pipeline.calibrate_heads)",
+                       "weights": "seeded random, " + ("heat head calibrated (pipeline.calibrate_heads)" if args.net == "rtpose" else "confidence filters calibrated (pipeline.calibrate_yolo_conf)"),
                        "parallelism": "frames sharded x%d, one all-gather of records" % world},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"] + " (dominant convolution instantiation: %.0f of %.0f conv us/step)" % (dom["us_per_step"], conv_ms.value * 1e3 / K),
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
@@ -237,12 +242,12 @@ def main():
                                         "ms_per_step": round(conv_ms.value / K, 4), "tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
                                         "stem_pool_ms_per_step": round(other_ms.value / K, 4), "by_kernel": kernels},
                          "measured": "HIP events around every conv launch on the launch stream, the same %d steps re-run eagerly on one engine right after the timed region (%.4f ms/step with events)" % (K, elapsed_profiled / K * 1e3)},
-            "frame_stats": {"mean_peaks": round(float(recs['n_peaks'].mean()), 2),
-                            "mean_persons": round(float(recs['n_persons'].mean()), 3),
+            "frame_stats": {"mean_peaks": round(float(recs['n_peaks' if args.net == "rtpose" else 'n_candidates'].mean()), 2),
+                            "mean_persons": round(float(recs['n_persons' if args.net == "rtpose" else 'n_det'].mean()), 3),
                             "overflow_frames": int((recs['status'] != 0).sum()),
                             "records_identical_across_steps_and_engines": same},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.net == "rtpose":
             out["cpu_baseline"] = cpu_baseline(engine, depth_host)
         print(json.dumps(out))
     if world > 1:

@@ -101,7 +101,7 @@ class YoloEngine:
 
     def __init__(self, precision="bf16", state_dict=None, device=None, max_batch=32, input_size=224,
                  w_org=480, h_org=640, intrinsics=INTRINSICS, weight_seed=1, anchors=None,
-                 conf_threshold=0.5, nms_threshold=0.5):
+                 conf_threshold=0.5, nms_threshold=0.5, private_ctx=False):
         from .config import YOLO_ANCHORS
         from .network.yolo_posenet import YoloPoseNet
         if not torch.cuda.is_available():
@@ -116,7 +116,7 @@ class YoloEngine:
         else:
             self.model.load_state_dict(state_dict)
         self.model.precision = precision
-        self.ctx = _lib.Context.for_device(self.device.index)
+        self.ctx = _lib.Context(self.device.index) if private_ctx else _lib.Context.for_device(self.device.index)
         self.L = _lib.lib()
         self.net = self.model._compile(self.device, self.max_batch, self.S, self.S)
         self.cfg = make_parse_cfg(default_cfg(), input_size=self.S, w_org=w_org, h_org=h_org, intrinsics=intrinsics,
