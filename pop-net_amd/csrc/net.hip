@@ -191,20 +191,27 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     }
 
     cs.cfg = pick_cfg(cout);
-    {   // bf16 stride-1 layers on maps that split into 24..30-column strips run conv3_kernel (conv3_kernel.h)
+    {   // bf16 stride-1 layers run conv3_kernel (conv3_kernel.h) when the map splits into column strips (<= 30 wide: the
+        // halo row is 32 pixels) whose 4-row tiles fill >= 75 % of a wave group's 112 pixel slots
         const Buf &ib0 = n->bufs[cs.in_buf];
-        const int segs = (ib0.W + 29) / 30, wt = (ib0.W + segs - 1) / segs;
-        if (n->prec == PN_PREC_BF16 && cs.stride == 1 && (ks == 3 || ks == 1) && wt >= 24 && cout > 32 && !getenv("POPNET_NO_CONV3")) {
+        int segs = 0, wt = 0, rows = 0;
+        double best = 0;
+        for (int sg = (ib0.W + 29) / 30; sg <= (ib0.W + 15) / 16; ++sg) {
+            const int w = (ib0.W + sg - 1) / sg, r = std::min(std::min(ib0.H, 4), 112 / w);
+            const double util = r * ((double)ib0.W / sg) / 112.0;
+            if (util > best + 1e-9) { best = util; segs = sg; wt = w; rows = r; }
+        }
+        if (n->prec == PN_PREC_BF16 && cs.stride == 1 && (ks == 3 || ks == 1) && best >= 0.75 && cout > 32 && !getenv("POPNET_NO_CONV3")) {
             cs.kern = 3;
             cs.wc = std::max(cout > 64 ? 4 : (cout > 32 ? 2 : 1), cs.wc_min);
-            const long tiles112 = (long)n->max_batch * ((ib0.H + 3) / 4) * segs;           // 4-row strip tiles
-            cs.wp = (cs.wc == 2 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;           // big maps: 8-row tiles, 256 threads
+            const long tiles112 = (long)n->max_batch * ((ib0.H + rows - 1) / rows) * segs;   // strip tiles of one wave group
+            cs.wp = (cs.wc == 2 && rows == 4 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;   // big maps: 8-row tiles, 256 threads
             const int hr = 4 * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
             // single halo image (4 waves / SIMD) beats the double-buffered variant (3 waves / SIMD) on every level
             // of both networks (profiles/README.md, r01 v8); POPNET_CONV3_NBUF2=1 selects the latter for experiments
             cs.nbuf = ((cs.cin_chunks > 1 || cs.nbuf_min == 2) && ks == 3 && ngw <= 18 && getenv("POPNET_CONV3_NBUF2")) ? 2 : 1;
             cs.Wt = wt;
-            cs.R = std::min(ib0.H, 4 * cs.wp);
+            cs.R = std::min(ib0.H, rows * cs.wp);          // rows * Wt <= 112 pixel slots per wave group, rows <= 4 halo-wise
         }
     }
     const int BC = cs.kern == 3 ? cs.wc * 32 : pn_cfg_couts(cs.cfg);

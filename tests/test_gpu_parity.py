@@ -136,6 +136,53 @@ def test_forward_other_input_sizes(gpu, golden):
         assert (got.cpu() - ref).abs().max() < 2e-4
 
 
+@pytest.mark.parametrize("hw", [(224, 224), (240, 320), (200, 232), (256, 192), (96, 480)])
+def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, monkeypatch):
+    """conv3_kernel (24..30-column strip tiles, partial last tiles, merged narrow convs) accumulates in the same k order
+    with the same MFMA as the generic kernel, so the bf16 maps must be IDENTICAL, for both networks and at sizes whose
+    maps are not multiples of 28 wide (200x232 -> 25x29 / 50x58 / 100x116; 256x192 -> 24-wide strips + 32-wide maps
+    that stay on the generic kernel).  And the bf16 rtpose maps stay within the stated tolerance of fp32."""
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    H, W = hw
+    x = torch.from_numpy(np.random.default_rng(6).normal(0, 1, (3, 1, H, W)).astype(np.float32)).to(gpu)
+
+    def yolo():
+        m = YoloPoseNet(15, input_dim=1).eval()
+        m.load_state_dict(state_dict_from_keys(golden.keys["yolo_posenet"], seed=1))
+        m.precision = "bf16"
+        return m
+
+    do_yolo = H % 16 == 0 and W % 16 == 0
+    got = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
+    got_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.setenv("POPNET_NO_CONV3", "1")          # read when the net is compiled
+    ref = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
+    ref_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.delenv("POPNET_NO_CONV3")
+    f32 = [t.clone() for t in _rtpose(golden, "fp32")(x)[0]]
+    torch.cuda.synchronize()
+    for a, b, c, name in zip(got, ref, f32, ("paf", "heat", "z")):
+        assert torch.isfinite(a).all() and torch.equal(a, b), name
+        d = (a - c).abs()
+        assert float(d.max()) < 0.15 and float(d.mean()) < 0.02, (name, float(d.max()), float(d.mean()))
+    if do_yolo:
+        assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y)
+
+
+def test_bf16_batch_invariance_and_ragged_batches(gpu, golden):
+    """Same as the fp32 invariance test, for the bf16 path (grouped launches, merged narrow convs, strip tiles)."""
+    m = _rtpose(golden, "bf16")
+    x = torch.from_numpy(np.random.default_rng(4).normal(0, 1, (7, 1, 224, 224)).astype(np.float32)).to(gpu)
+    (p7, h7, z7), _ = m(x)
+    p7, h7, z7 = p7.clone(), h7.clone(), z7.clone()
+    (p1, h1, z1), _ = m(x[5:6])
+    p1, h1, z1 = p1.clone(), h1.clone(), z1.clone()
+    (p2, h2, z2), _ = m(x[[6, 1]])
+    torch.cuda.synchronize()
+    assert torch.equal(p7[5:6], p1) and torch.equal(h7[5:6], h1) and torch.equal(z7[5:6], z1)
+    assert torch.equal(p7[[6, 1]], p2) and torch.equal(h7[[6, 1]], h2) and torch.equal(z7[[6, 1]], z2)
+
+
 # ---------------------------------------------------------------------------------------------
 # Open-Pose+ parsing
 # ---------------------------------------------------------------------------------------------
