@@ -33,14 +33,18 @@ __device__ __forceinline__ void pn_glds16(gcptr src, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 
-template <int KS, int WC, int WP, int NBUF>
-__global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void conv3_kernel(const ConvProblem *__restrict__ probs) {
+// PT = pixel tiles of 16 per wave: 7 (112 pixels = 4 rows of a 28-column strip, 56 accumulator VGPRs, 4 waves / SIMD) or
+// 14 (224 pixels = 8 rows, 112 accumulator VGPRs, 2 waves / SIMD: half the weight bytes per MFMA, for Cin = 64 layers
+// on large maps, whose 224-pixel tiles otherwise stream their whole weight slice twice).
+template <int KS, int WC, int WP, int NBUF, int PT>
+__global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CONV3_OCC)) void conv3_kernel(const ConvProblem *__restrict__ probs) {
     typedef __bf16 T;
     typedef Elem<PN_PREC_BF16>::Frag Frag;
-    constexpr int CT = 2, PT = 7, NT = WC * WP * 64, NW = WC * WP;
+    constexpr int CT = 2, NT = WC * WP * 64, NW = WC * WP;
+    constexpr int RPG = PT * 4 / 7;                    // output rows of a 28-column strip per wave group
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int PITCH = 32;                          // halo pixels per LDS row
-    constexpr int HR = 4 * WP + KS - 1 + ((KS - 1) & 1 ? 1 : 0);   // halo rows (even: one DMA fills two rows)
+    constexpr int HR = RPG * WP + KS - 1 + ((KS - 1) & 1 ? 1 : 0);   // halo rows (even: one DMA fills two rows)
     constexpr int PS = HR * PITCH * 16;                // bytes of one piece plane (multiple of 256)
     constexpr int NG = 8 * (HR / 2);                   // DMA instructions per chunk, spread over the waves
     constexpr int FRAGB = 1024;
@@ -175,8 +179,10 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
         for (int j = 0; j < DB - 1; ++j) bq[j] = read_b_frag<PN_PREC_BF16>(sm + PN3_OFF(j), baddr[j % PT]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
-        for (int j = 0; j < NITEM; ++j) {
-            const int s = j / PT, pt = j % PT;
+        for (int s = 0; s < NSTEP; ++s) {
+#pragma clang loop unroll(full)
+          for (int pt = 0; pt < PT; ++pt) {
+            const int j = s * PT + pt;
             if (pt == 0) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {        // wpack ends with NA-1 spare fragments
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
             if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x020, CT, 0);
             if (jr < NITEM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+        }
         }
 #undef PN3_OFF
         }
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
     const int pix0 = (b * Ho + oy0) * Wo + ox0;
     auto finish = [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;
-#pragma unroll
+#pragma clang loop unroll(full)                          // a rolled loop would index acc[] dynamically = scratch memory
         for (int pt = 0; pt < PT; ++pt) {
             const int slot = (wp * PT + pt) * 16 + c;
             if (slot >= npix || cw >= cout) continue;
@@ -298,9 +305,9 @@ __global__ __launch_bounds__(WC * WP * 64, NBUF == 2 ? 3 : PN_CONV3_OCC) void co
     PN_STAMP_AT(12);
 }
 
-template <int KS, int WC, int WP, int NBUF>
+template <int KS, int WC, int WP, int NBUF, int PT = 7>
 static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
-    auto kern = conv3_kernel<KS, WC, WP, NBUF>;
+    auto kern = conv3_kernel<KS, WC, WP, NBUF, PT>;
     if (L.lds_bytes > 48 * 1024) {
         static size_t configured = 0;   // per instantiation
         if (configured < L.lds_bytes) {
@@ -314,7 +321,9 @@ static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream
     return PN_OK;
 }
 #define PN3_CASE(KS, WC, WP, NB) \
-    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
+#define PN3_CASE_PT(KS, WC, WP, NB, PT_) \
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == PT_) return conv3_launch_one<KS, WC, WP, NB, PT_>(ctx, L, stream);
 int pn_launch_conv3_part0(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 int pn_launch_conv3_part1(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 int pn_launch_conv3_part2(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
