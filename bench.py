@@ -111,7 +111,11 @@ def main():
     K, W = args.steps, args.warmup
     item = REC.itemsize
     frames_dev = torch.empty((K, BATCH, item), device=dev, dtype=torch.uint8)
-    gathered = torch.empty((world * K * BATCH, item), device=dev, dtype=torch.uint8) if world > 1 else None
+    # what crosses xGMI in the closing all-gather: compact pn_pose_wire records (6.2 KB instead of 33 KB per frame) for
+    # the PAF path, the (already small) pn_yolo_frame records for the yolo path
+    witem = _lib.POSE_WIRE_DTYPE.itemsize if args.net == "rtpose" else item
+    wire_dev = torch.empty((K, BATCH, witem), device=dev, dtype=torch.uint8) if world > 1 else None
+    gathered = torch.empty((world * K * BATCH, witem), device=dev, dtype=torch.uint8) if world > 1 else None
 
     frames_static = [torch.empty((BATCH, item), device=dev, dtype=torch.uint8) for _ in range(PIPE)]
     host_static = [torch.empty((BATCH, item), dtype=torch.uint8, pin_memory=True) for _ in range(PIPE)]
@@ -130,7 +134,12 @@ def main():
                 graphs[e].replay()
             else:
                 step_body(e)
-            frames_dev[k].copy_(frames_static[e], non_blocking=True)      # keep every step's records for the final gather
+            frames_dev[k].copy_(frames_static[e], non_blocking=True)      # keep every step's records (rank-0 statistics)
+            if world > 1:                                                  # ... and their wire form for the final gather
+                if args.net == "rtpose":
+                    engines[e].pack(frames_static[e], wire_dev[k])
+                else:
+                    wire_dev[k].copy_(frames_static[e], non_blocking=True)
 
     def join():
         cur = torch.cuda.current_stream(dev)
@@ -157,7 +166,7 @@ def main():
             step(i % K)
     join()
     if world > 1:
-        dist.all_gather_into_tensor(gathered, frames_dev.view(K * BATCH, item))
+        dist.all_gather_into_tensor(gathered, wire_dev.view(K * BATCH, witem))
     torch.cuda.synchronize()
 
     # ---- timed region: K steps, barrier + device sync on both sides, max over ranks ----
@@ -169,7 +178,7 @@ def main():
         step(k)
     join()
     if world > 1:
-        dist.all_gather_into_tensor(gathered, frames_dev.view(K * BATCH, item))
+        dist.all_gather_into_tensor(gathered, wire_dev.view(K * BATCH, witem))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

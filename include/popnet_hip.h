@@ -183,6 +183,22 @@ int pn_retrieve_depth(pn_ctx *ctx, const float *depthmap_dev, float *heatmap_dev
                       const int *centers_xy_dev, int n, int radius, float *out_dev, void *hip_stream);
 size_t pn_sizeof_pose_frame(void);
 
+/* Compact wire form of pn_pose_frame for the multi-GPU gather ("[frames, P_max, 15, 6] float32 +
+ * count"): what crosses xGMI / PCIe when only the per-person results are needed (6.2 KB instead of 33 KB per
+ * frame).  vals = (x, y) in the original frame, (X, Y, Z) metres, part confidence, rounded to float32 from the
+ * float64 record; person_joint = the peak ids of person_to_joint_assoc (-1 = missing), so assignments stay exact.
+ * Frames with more than PN_WIRE_MAX_PERSONS persons set PN_FRAME_OVERFLOW_PERSONS in status and keep the first
+ * PN_WIRE_MAX_PERSONS rows (n_persons still holds the true count). */
+#define PN_WIRE_MAX_PERSONS 16
+typedef struct pn_pose_wire {
+    int32_t  n_persons;
+    uint32_t status;
+    int16_t  person_joint[PN_WIRE_MAX_PERSONS][PN_NUM_JOINTS];
+    float    vals[PN_WIRE_MAX_PERSONS][PN_NUM_JOINTS][6];
+} pn_pose_wire;
+int pn_pack_pose_frames(pn_ctx *ctx, const pn_pose_frame *frames_dev, int B, pn_pose_wire *wire_dev, void *hip_stream);
+size_t pn_sizeof_pose_wire(void);
+
 /* ---- Yolo-Pose+ decode ----------------------------------------------------------------------
  * Replaces parse_prior_pose (tpm/lib/utils/prior_pose_align.py:10-168, pred_vis=False), quirks
  * included (candidate order anchor-major; suppression loop over rows 1..n-2; inclusive

@@ -63,6 +63,13 @@ YOLO_FRAME_DTYPE = np.dtype([
     ("bbox_org", np.float32, (PN_YOLO_MAX_DET, 4)),
 ], align=True)
 
+PN_WIRE_MAX_PERSONS = 16
+POSE_WIRE_DTYPE = np.dtype([
+    ("n_persons", np.int32), ("status", np.uint32),
+    ("person_joint", np.int16, (PN_WIRE_MAX_PERSONS, PN_NUM_JOINTS)),
+    ("vals", np.float32, (PN_WIRE_MAX_PERSONS, PN_NUM_JOINTS, 6)),      # x, y (original frame), X, Y, Z (m), part confidence
+], align=True)
+
 _lib = None
 
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -89,6 +96,8 @@ _SIGNATURES = {
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_sizeof_pose_frame": (_sz, []),
+    "pn_pack_pose_frames": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "pn_sizeof_pose_wire": (_sz, []),
     "pn_sizeof_yolo_frame": (_sz, []),
     "pn_debug_cubic_coeffs": (None, [_f, C.POINTER(C.c_float)]),
     "process_paf": (_i, [_i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
@@ -123,6 +132,8 @@ def lib():
     if handle.pn_sizeof_pose_frame() != POSE_FRAME_DTYPE.itemsize:
         raise PopnetError("pn_pose_frame layout mismatch: C %d vs numpy %d"
                           % (handle.pn_sizeof_pose_frame(), POSE_FRAME_DTYPE.itemsize))
+    if handle.pn_sizeof_pose_wire() != POSE_WIRE_DTYPE.itemsize:
+        raise PopnetError("pn_pose_wire layout mismatch: C %d vs numpy %d" % (handle.pn_sizeof_pose_wire(), POSE_WIRE_DTYPE.itemsize))
     if handle.pn_sizeof_yolo_frame() != YOLO_FRAME_DTYPE.itemsize:
         raise PopnetError("pn_yolo_frame layout mismatch")
     _lib = handle

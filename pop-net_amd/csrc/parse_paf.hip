@@ -573,6 +573,40 @@ __global__ void retrieve_depth_kernel(const float *__restrict__ dm, const float 
     out[t] = sp / sw;
 }
 
+// one thread per (frame, person slot, joint): float64 record -> float32 wire values
+__global__ __launch_bounds__(256) void pack_pose_kernel(const pn_pose_frame *__restrict__ frames, int B, pn_pose_wire *__restrict__ wire) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = PN_WIRE_MAX_PERSONS * PN_NUM_JOINTS;
+    if (i >= B * per) return;
+    const int f = i / per, r = i - f * per, p = r / PN_NUM_JOINTS, j = r - p * PN_NUM_JOINTS;
+    const pn_pose_frame &fr = frames[f];
+    pn_pose_wire &w = wire[f];
+    const int n = fr.n_persons;
+    if (r == 0) {
+        w.n_persons = n;
+        w.status = fr.status | (n > PN_WIRE_MAX_PERSONS ? PN_FRAME_OVERFLOW_PERSONS : 0u);
+    }
+    const bool live = p < n;
+    w.person_joint[p][j] = live ? (int16_t)fr.person_joint[p][j] : (int16_t)-1;
+    w.vals[p][j][0] = live ? (float)fr.joints_2d[p][j][0] : 0.f;
+    w.vals[p][j][1] = live ? (float)fr.joints_2d[p][j][1] : 0.f;
+    w.vals[p][j][2] = live ? (float)fr.joints_3d[p][j][0] : 0.f;
+    w.vals[p][j][3] = live ? (float)fr.joints_3d[p][j][1] : 0.f;
+    w.vals[p][j][4] = live ? (float)fr.joints_3d[p][j][2] : 0.f;
+    w.vals[p][j][5] = live ? (float)fr.part_conf[p][j] : 0.f;
+}
+
+extern "C" int pn_pack_pose_frames(pn_ctx *ctx, const pn_pose_frame *frames_dev, int B, pn_pose_wire *wire_dev, void *hip_stream) {
+    if (!ctx) return PN_ERR_INVALID;
+    if (!frames_dev || !wire_dev || B < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_pack_pose_frames: bad arguments");
+    const int total = B * PN_WIRE_MAX_PERSONS * PN_NUM_JOINTS;
+    hipLaunchKernelGGL(pack_pose_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, frames_dev, B, wire_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+extern "C" size_t pn_sizeof_pose_wire(void) { return sizeof(pn_pose_wire); }
+
 extern "C" int pn_retrieve_depth(pn_ctx *ctx, const float *depthmap_dev, float *heatmap_dev, int h, int w,
                                  const int *centers_xy_dev, int n, int radius, float *out_dev, void *hip_stream) {
     if (!ctx) return PN_ERR_INVALID;

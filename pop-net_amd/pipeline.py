@@ -92,6 +92,16 @@ class PoseEngine:
     def predict_host(self, depth):
         return records_to_numpy(self.predict(depth))
 
+    def pack(self, frames, wire=None):
+        """pn_pose_frame records (device, [B, sizeof]) -> compact pn_pose_wire records (device uint8 [B, sizeof], no sync):
+        the form that is gathered across GPUs (6.2 KB instead of 33 KB per frame)."""
+        B = frames.shape[0]
+        if wire is None:
+            wire = torch.empty((B, _lib.POSE_WIRE_DTYPE.itemsize), device=frames.device, dtype=torch.uint8)
+        self.ctx.check(self.L.pn_pack_pose_frames(self.ctx.handle, C.c_void_p(frames.data_ptr()), B, C.c_void_p(wire.data_ptr()),
+                                                  _lib.current_stream_ptr(self.device)), "pn_pack_pose_frames")
+        return wire[:B]
+
 
 class YoloEngine:
     """Batched Yolo-Pose+ twin of PoseEngine: depth frames -> pn_preprocess -> pn_yolo_forward ->
@@ -193,6 +203,19 @@ def calibrate_yolo_conf(model, device=None, frac=0.012, calib_frames=8, seed=99)
     model.precision = prec
     model.invalidate()
     return model
+
+
+def wire_to_lists(wire):
+    """pn_pose_wire records (numpy) -> the per-frame result-schema entries (float32 values widened to Python floats)."""
+    out = {"human_pred_set_2d": [], "human_pred_set_3d": [], "human_pred_set_visibility": [], "human_pred_set_part_conf": []}
+    for fr in wire:
+        n = min(int(fr["n_persons"]), _lib.PN_WIRE_MAX_PERSONS)
+        v = fr["vals"][:n].astype(np.float64)
+        out["human_pred_set_2d"].append(v[:, :, 0:2].tolist())
+        out["human_pred_set_3d"].append(v[:, :, 2:5].tolist())
+        out["human_pred_set_part_conf"].append(v[:, :, 5].tolist())
+        out["human_pred_set_visibility"].append((fr["person_joint"][:n] >= 0).astype(int).tolist())
+    return out
 
 
 def records_to_numpy(frames_dev):

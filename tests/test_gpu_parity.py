@@ -578,3 +578,26 @@ def test_evaluate_mpreal_script_matches_reference_scripts(gpu, golden, tmp_path,
         if net == "rtpose":
             assert data["human_pred_set_visibility"][b] == s["human_pred_set_visibility"][b]
     assert out is not None and len(out["ap2d"]) == 16 and len(out["pck3d"]) == 15
+
+
+def test_wire_records_match_full_records(gpu):
+    """pn_pack_pose_frames: the compact records gathered across GPUs carry the same persons, the same joint assignment
+    (exact) and the float32 rounding of the float64 values."""
+    from popnet_amd.pipeline import PoseEngine, records_to_numpy, wire_to_lists
+    from popnet_amd.dataset import pose_records_to_lists
+    eng = PoseEngine(precision="bf16", device=gpu, max_batch=8)
+    depth = torch.from_numpy(synth.synth_depth(8, 640, 480, seed=11)).to(gpu)
+    frames = eng.predict(depth)
+    wire = eng.pack(frames).cpu().numpy().view(_lib.POSE_WIRE_DTYPE).reshape(-1)
+    full = records_to_numpy(frames)
+    assert int(full["n_persons"].sum()) > 0
+    for w, f in zip(wire, full):
+        n = int(f["n_persons"])
+        assert int(w["n_persons"]) == n and int(w["status"]) == int(f["status"]) and n <= _lib.PN_WIRE_MAX_PERSONS
+        assert np.array_equal(w["person_joint"][:n], f["person_joint"][:n].astype(np.int16)) and np.all(w["person_joint"][n:] == -1)
+        assert np.array_equal(w["vals"][:n, :, 0:2], f["joints_2d"][:n].astype(np.float32))
+        assert np.array_equal(w["vals"][:n, :, 2:5], f["joints_3d"][:n].astype(np.float32))
+        assert np.array_equal(w["vals"][:n, :, 5], f["part_conf"][:n].astype(np.float32))
+    a, b = wire_to_lists(wire), pose_records_to_lists(full)
+    assert a["human_pred_set_visibility"] == b["human_pred_set_visibility"]
+    assert np.allclose(np.array(a["human_pred_set_3d"][0]), np.array(b["human_pred_set_3d"][0]), atol=1e-5) or len(a["human_pred_set_3d"][0]) == 0
