@@ -523,6 +523,9 @@ extern "C" int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf
     for (int p = 0; p < 8; ++p) host_cubic_coeffs((float)(2 * p + 1) / 16.0f, tab.c[p]);
     hipStream_t s = (hipStream_t)hip_stream;
     ParseWs *ws = (ParseWs *)ctx->parse_ws;
+    // rows beyond n_peaks / n_persons are not written by the kernels: zero them, so that a record is a pure function of
+    // its frame (bit-identical wherever in a batch, and in whatever buffer, the frame was processed)
+    PN_HIP_CHECK(ctx, hipMemsetAsync(frames_dev, 0, (size_t)B * sizeof(pn_pose_frame), s));
     hipLaunchKernelGGL(peaks_refine_kernel, dim3(J_, B), dim3(256), 0, s, heat_dev, h, w, J_ + 1, cfg->thresh_heatmap, tab, ws);
     hipLaunchKernelGGL(limb_match_kernel, dim3(L_, B), dim3(256), 0, s, paf_dev, h, w, 2 * L_, cfg->thresh_paf,
                        h * cfg->downsample, tab, ws);

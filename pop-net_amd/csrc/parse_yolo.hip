@@ -200,6 +200,7 @@ extern "C" int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int 
     if (num_anchors * h * w > YMAXC) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_yolo: %d cells exceed %d", num_anchors * h * w, YMAXC);
     float a[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 2 * num_anchors; ++i) a[i] = anchors_wh[i];
+    PN_HIP_CHECK(ctx, hipMemsetAsync(frames_dev, 0, (size_t)B * sizeof(pn_yolo_frame), (hipStream_t)hip_stream));   // unused rows read as zero
     hipLaunchKernelGGL(parse_yolo_kernel, dim3(B), dim3(256), 0, (hipStream_t)hip_stream, posemaps_dev, h, w, num_anchors,
                        num_joints, a[0], a[1], a[2], a[3], a[4], a[5], (float)w_out, (float)h_out, depth_mean, depth_std,
                        conf_threshold, nms_threshold, (float)vis_margin, glue ? 1 : 0, glue ? (float)glue->input_size : 1.f,

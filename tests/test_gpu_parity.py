@@ -601,3 +601,22 @@ def test_wire_records_match_full_records(gpu):
     a, b = wire_to_lists(wire), pose_records_to_lists(full)
     assert a["human_pred_set_visibility"] == b["human_pred_set_visibility"]
     assert np.allclose(np.array(a["human_pred_set_3d"][0]), np.array(b["human_pred_set_3d"][0]), atol=1e-5) or len(a["human_pred_set_3d"][0]) == 0
+
+
+def test_full_batch_permutation_equivariance_and_single_frame_consistency(gpu):
+    """BASELINE configs[1] size (32 frames, bf16), size-independent properties of the whole path: frames are
+    independent, so permuting the batch permutes the records bit for bit, and a frame processed alone gives the record
+    it got inside the full batch (different tile counts, same per-frame arithmetic)."""
+    from popnet_amd.pipeline import PoseEngine
+    eng = PoseEngine(precision="bf16", device=gpu, max_batch=32)
+    depth = torch.from_numpy(synth.synth_depth(32, 640, 480, seed=21)).to(gpu)
+    base = eng.predict(depth).clone()
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(32)).to(gpu)
+    shuffled = eng.predict(depth[perm]).clone()
+    singles = [eng.predict(depth[i:i + 1]).clone() for i in (0, 13, 31)]
+    torch.cuda.synchronize()
+    assert torch.equal(shuffled, base[perm])
+    for i, s in zip((0, 13, 31), singles):
+        assert torch.equal(s[0], base[i])
+    recs = base.cpu().numpy().view(_lib.POSE_FRAME_DTYPE).reshape(-1)
+    assert int((recs["status"] != 0).sum()) == 0 and int(recs["n_peaks"].sum()) > 0
