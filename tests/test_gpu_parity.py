@@ -620,3 +620,43 @@ def test_full_batch_permutation_equivariance_and_single_frame_consistency(gpu):
         assert torch.equal(s[0], base[i])
     recs = base.cpu().numpy().view(_lib.POSE_FRAME_DTYPE).reshape(-1)
     assert int((recs["status"] != 0).sum()) == 0 and int(recs["n_peaks"].sum()) > 0
+
+
+def test_yolo_full_batch_permutation_equivariance(gpu):
+    from popnet_amd.pipeline import YoloEngine
+    eng = YoloEngine(precision="bf16", device=gpu, max_batch=32)
+    depth = torch.from_numpy(synth.synth_depth(32, 640, 480, seed=22)).to(gpu)
+    base = eng.predict(depth).clone()
+    perm = torch.from_numpy(np.random.default_rng(4).permutation(32)).to(gpu)
+    shuffled = eng.predict(depth[perm]).clone()
+    single = eng.predict(depth[7:8]).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(shuffled, base[perm]) and torch.equal(single[0], base[7])
+
+
+@pytest.mark.parametrize("shape,dtype", [((240, 320), np.float16), ((240, 320), np.float32), ((512, 480), np.float16)])
+def test_engine_other_frame_sizes_and_dtypes(gpu, shape, dtype):
+    """ITOP-sized (240x320) and 512-row frames, f16 and f32 storage: pre-processing equals the oracle bit for bit and the
+    records equal the oracle parse of the maps (the rescale uses the engine's w_org / h_org)."""
+    from oracle import parse_paf as O, preproc as opre
+    from popnet_amd.pipeline import PoseEngine, records_to_numpy
+    from popnet_amd.utils.paf_to_pose import frame_assoc
+    H, W = shape
+    eng = PoseEngine(precision="fp32", device=gpu, max_batch=3, w_org=W, h_org=H)
+    depth = synth.synth_depth(3, H, W, seed=31, dtype=dtype)
+    recs = records_to_numpy(eng.predict(torch.from_numpy(depth).to(gpu)))
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.x[:3].cpu().numpy(), opre.preprocess_batch(depth))
+    hp, hh, hz = (t[:3].cpu().numpy().transpose(0, 2, 3, 1) for t in (eng.paf, eng.heat, eng.z))
+    compared = 0
+    for b in range(3):
+        if int(recs[b]["status"]):          # the head calibration is for 480x640 statistics: a crowded map may hit the
+            continue                        # compile-time person-row limit, which is flagged, never silent
+        compared += 1
+        ref = O.frame_to_records(hh[b].copy(), hp[b].copy(), hz[b].copy(), w_org=W, h_org=H)
+        a = frame_assoc(recs[b])
+        assert a.shape[0] == len(ref["humans_3d"])
+        if a.shape[0]:
+            assert np.array_equal(recs[b]["joints_2d"][:a.shape[0]], np.array(ref["humans_2d"]).reshape(-1, 15, 2))
+            assert np.array_equal(recs[b]["joints_3d"][:a.shape[0]], np.array(ref["humans_3d"]).reshape(-1, 15, 3))
+    assert compared >= 1
