@@ -25,6 +25,7 @@ def golden():
         keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
         script = json.load(open(os.path.join(GOLDEN, "script_eval_data.json")))
         script_yolo = json.load(open(os.path.join(GOLDEN, "script_eval_data_yolo.json")))
+        script_metrics = json.load(open(os.path.join(GOLDEN, "script_metrics.json")))
     return G
 
 

@@ -519,13 +519,91 @@ def golden_metrics():
     json.dump(out, open(os.path.join(HERE, "metrics.json"), "w"))
 
 
+# ---- F9: end-to-end metrics: the reference's evaluation script + its own metric code on a 12-frame synthetic split ----
+def golden_script_metrics():
+    """12 synthetic frames through the reference evaluation script (same checkpoint recipe as F6), ground truth derived from
+    its own predictions (jittered, some persons dropped) so that PCK / mAP are non-trivial, metrics by util/eval_pck.py and
+    util/eval_mAP.py.  The GPU test feeds the same frames + labels to scripts/evaluate_mpreal.py and compares the metrics."""
+    import contextlib
+    import copy
+    import io
+    import torch
+    from popnet_amd import synth
+    from lib.network.rtpose_light3d import rtpose_light3d
+    N = 12
+    work = tempfile.mkdtemp(prefix="popnet_fake_ds_metrics_")
+    img_dir = os.path.join(work, "depth_maps")
+    os.makedirs(img_dir)
+    frames = synth.synth_depth(N, 640, 480, seed=79)
+    intr = {"fx": 504.1189880371094, "fy": 504.042724609375, "cx": 231.7421875, "cy": 320.62640380859375}
+    labels = {"intrinsics": intr}
+    for i in range(N):
+        np.save(os.path.join(img_dir, "f%02d.npy" % i), frames[i])
+        labels["f%02d.npy" % i] = [{"2d_joints": [[10.0 + j, 20.0] for j in range(15)], "3d_joints": [[0.0, 0.0, 3.0]] * 15}]
+    ann = os.path.join(work, "labels.json")
+    json.dump(labels, open(ann, "w"))
+    model = rtpose_light3d(15, 14, 2, input_dim=1).eval()
+    arrays = synth.fill_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(np_sd(arrays))
+    x = np.stack([reference_preprocess(f, 6) for f in frames[:4]]).astype(np.float32)
+    shift = calibrated_heat_bias(model, x)
+    arrays["model2_2.12.bias"][:15] += shift
+    ckpt = os.path.join(work, "ckpt.pth")
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in arrays.items()}, ckpt)
+    outdir = os.path.join(work, "out")
+    argv, cwd = sys.argv, os.getcwd()
+    try:
+        os.chdir(os.path.join(TPM, "evaluate"))
+        sys.argv = ["eval", "--annotations", ann, "--image-dir", img_dir, "--w-org", "480", "--h-org", "640",
+                    "--batch-size", "4", "--weight", ckpt, "--output-dir", outdir]
+        import matplotlib
+        matplotlib.use("Agg")
+        with contextlib.redirect_stdout(io.StringIO()):
+            runpy.run_path(os.path.join(TPM, "evaluate", "evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    data = json.load(open(os.path.join(outdir, "eval_data.json")))
+    p2, p3, pc = data["human_pred_set_2d"], data["human_pred_set_3d"], data["human_pred_set_part_conf"]
+    rng = np.random.default_rng(17)
+    g2, g3 = [], []
+    for f in range(N):
+        G2, G3 = [], []
+        for h2, h3 in zip(p2[f], p3[f]):
+            a2, a3 = np.array(h2, dtype=np.float64), np.array(h3, dtype=np.float64)
+            vis = ~((a2[:, 0] == -1) & (a2[:, 1] == -1))
+            if vis.sum() < 6 or rng.random() < 0.2:
+                continue
+            a2[~vis] = a2[vis].mean(0); a3[~vis] = a3[vis].mean(0)            # ground truth has every joint
+            G2.append((a2 + rng.normal(0, 4.0, a2.shape)).tolist())
+            G3.append((a3 + rng.normal(0, 0.04, a3.shape)).tolist())
+        if not G2:                                                            # the reference's mAP code needs >= 1 GT person per image
+            G2.append(rng.uniform(50, 400, (15, 2)).tolist()); G3.append(rng.uniform(-1, 4, (15, 3)).tolist())
+        g2.append(G2); g3.append(G3)
+    sys.path.insert(0, REF)
+    from util import eval_pck as RP, eval_mAP as RA, util_functions as RU
+    names = RU.get_keypoints()
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+        d2, k2 = RP.eval_human_dataset_2d_PCKh(copy.deepcopy(p2), copy.deepcopy(g2), num_joints=15, head_id=0, neck_id=1, iou_th=0.5)
+        d3, k3 = RP.eval_human_dataset_3d(copy.deepcopy(p2), copy.deepcopy(g2), copy.deepcopy(p3), copy.deepcopy(g3), num_joints=15, dist_th=0.1, iou_th=0.5)
+        a2 = RA.eval_ap_mpii_v2(copy.deepcopy(p2), copy.deepcopy(pc), copy.deepcopy(g2), gt_visibility_set=[], head_id=0, neck_id=1, joint_names=names, thresh=0.5)
+        a3 = RA.eval_ap_3D(copy.deepcopy(p3), copy.deepcopy(pc), copy.deepcopy(g3), gt_visibility_set=[], joint_names=names, thresh=0.1)
+    out = {"depth_seed": 79, "weight_seed": 0, "n_frames": N, "heat_bias_shift": shift.tolist(), "gt_2d": g2, "gt_3d": g3,
+           "persons_per_frame": [len(f) for f in p2],
+           "pck2d": [float(v) for v in k2], "err2d": [float(v) for v in d2], "pck3d": [float(v) for v in k3], "err3d": [float(v) for v in d3],
+           "ap2d": np.asarray(a2).tolist(), "ap3d": np.asarray(a3).tolist()}
+    json.dump(out, open(os.path.join(HERE, "script_metrics.json"), "w"))
+    print("F9: persons/frame", out["persons_per_frame"], "GT/frame", [len(f) for f in g2])
+    print("F9: PCK2D %.3f PCK3D %.3f AP2D %.2f AP3D %.2f" % (np.nanmean(k2), np.nanmean(k3), a2[-1], a3[-1]))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate golden vectors"
     install_shims()
     import popnet_amd  # noqa: F401
-    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics"]
+    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics"]
     fns = {"keys": golden_state_dicts, "forward": golden_forward, "parse": golden_parse, "yolo": golden_yolo,
            "pafprocess": golden_pafprocess, "script": golden_script,
-           "script_yolo": golden_script_yolo, "metrics": golden_metrics}
+           "script_yolo": golden_script_yolo, "metrics": golden_metrics, "script_metrics": golden_script_metrics}
     for w in which:
         fns[w]()
