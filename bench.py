@@ -99,15 +99,19 @@ def main():
     Engine = PoseEngine if args.net == "rtpose" else YoloEngine
     REC = _lib.POSE_FRAME_DTYPE if args.net == "rtpose" else _lib.YOLO_FRAME_DTYPE
 
-    # PIPE engines (own activations, parse workspace, record buffers, HIP stream and step graph): batch
-    # k runs on engine k % PIPE, so the latency-bound tail of one batch (small head convs, pose parsing,
-    # the record D2H copy) overlaps with the convolutions of the next.  Every batch still runs the whole
-    # path; only its latency, not the work, is hidden.
+    # popnet_amd.pipeline.StreamingEngine: PIPE batches in flight (per slot: engine = activations + parse workspace,
+    # static input, record buffers, HIP stream, ONE hipGraph of the whole step).  Batch k runs on slot k % PIPE, so the
+    # latency-bound tail of one batch (head convs, pose parsing, the record D2H copy) overlaps with the convolutions of
+    # the next.  Every batch still runs the whole path; only its latency, not the work, is hidden.
+    from popnet_amd.pipeline import StreamingEngine
     PIPE = max(1, args.pipeline)
-    engines = [Engine(precision=args.precision, device=dev, max_batch=BATCH, private_ctx=PIPE > 1) for _ in range(PIPE)]
+    se = StreamingEngine(Engine, depth=PIPE, graph=not args.no_graph, precision=args.precision, device=dev, max_batch=BATCH)
+    engines, streams = se.engines, se.streams
     engine = engines[0]
     depth_host = synth.synth_depth(BATCH, 640, 480, seed=1234 + rank)
-    depth = torch.from_numpy(depth_host).to(dev)
+    for sl in range(PIPE):
+        se.input(sl).copy_(torch.from_numpy(depth_host))          # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
     K, W = args.steps, args.warmup
     item = REC.itemsize
     frames_dev = torch.empty((K, BATCH, item), device=dev, dtype=torch.uint8)
@@ -117,53 +121,22 @@ def main():
     wire_dev = torch.empty((K, BATCH, witem), device=dev, dtype=torch.uint8) if world > 1 else None
     gathered = torch.empty((world * K * BATCH, witem), device=dev, dtype=torch.uint8) if world > 1 else None
 
-    frames_static = [torch.empty((BATCH, item), device=dev, dtype=torch.uint8) for _ in range(PIPE)]
-    host_static = [torch.empty((BATCH, item), dtype=torch.uint8, pin_memory=True) for _ in range(PIPE)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(PIPE)]
-    graphs = [None] * PIPE
-
-    def step_body(e):
-        """one step: preprocess -> forward -> parse -> records to pinned host memory (all async)"""
-        engines[e].predict(depth, frames_static[e])
-        host_static[e].copy_(frames_static[e], non_blocking=True)
-
     def step(k):
-        e = k % PIPE
-        with torch.cuda.stream(streams[e]):
-            if graphs[e] is not None:
-                graphs[e].replay()
-            else:
-                step_body(e)
-            frames_dev[k].copy_(frames_static[e], non_blocking=True)      # keep every step's records (rank-0 statistics)
+        t = se.submit()
+        with torch.cuda.stream(se.stream(t)):
+            frames_dev[k].copy_(se.records(t), non_blocking=True)          # keep every step's records (rank-0 statistics)
             if world > 1:                                                  # ... and their wire form for the final gather
                 if args.net == "rtpose":
-                    engines[e].pack(frames_static[e], wire_dev[k])
+                    engines[t % PIPE].pack(se.records(t), wire_dev[k])
                 else:
-                    wire_dev[k].copy_(frames_static[e], non_blocking=True)
+                    wire_dev[k].copy_(se.records(t), non_blocking=True)
 
     def join():
-        cur = torch.cuda.current_stream(dev)
-        for st in streams:
-            cur.wait_stream(st)
+        se.join()
 
-    for st in streams:
-        st.wait_stream(torch.cuda.current_stream(dev))
+    se.capture()
     for i in range(max(W, 2 * PIPE)):
         step(i % K)
-    torch.cuda.synchronize()
-    if not args.no_graph:
-        # the whole step (35 launches + the D2H copy) as ONE hipGraph per engine: removes per-launch host
-        # work and stream bubbles; the kernels and their arguments are exactly the eager ones
-        for e in range(PIPE):
-            with torch.cuda.stream(streams[e]):
-                step_body(e)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=streams[e]):
-                step_body(e)
-            graphs[e] = g
-        for i in range(2 * PIPE):
-            step(i % K)
     join()
     if world > 1:
         dist.all_gather_into_tensor(gathered, wire_dev.view(K * BATCH, witem))
@@ -192,20 +165,19 @@ def main():
     # ---- roofline pass: the same K steps again, eager, every conv launch bracketed by HIP events on
     # the launch stream (event records inside the throughput pass would perturb it) ----
     L = _lib.lib()
-    graphs_saved, graphs, PIPE_saved = graphs, [None], PIPE
-    PIPE = 1                                                     # engine 0 alone, eager, on its stream
     torch.cuda.synchronize()
-    L.pn_net_profile_begin(engine.net)
+    L.pn_net_profile_begin(engine.net)                           # only slot 0's net records events: its launches alone
     t1 = time.perf_counter()
-    for k in range(K):
-        step(k)
+    with torch.cuda.stream(streams[0]):
+        for k in range(K):
+            engine.predict(se.input(0), se.records(0))
+            se.host_records(0).copy_(se.records(0), non_blocking=True)
     torch.cuda.synchronize()
     elapsed_profiled = time.perf_counter() - t1
     conv_ms, other_ms, conv_flops = C.c_double(), C.c_double(), C.c_double()
     conv_n, other_n = C.c_int64(), C.c_int64()
     engine.ctx.check(L.pn_net_profile_end(engine.net, C.byref(conv_ms), C.byref(conv_n), C.byref(conv_flops),
                                           C.byref(other_ms), C.byref(other_n)), "pn_net_profile_end")
-    graphs, PIPE = graphs_saved, PIPE_saved
     kernels = []                                                # per instantiation, dominant first
     for r in range(16):
         name = C.create_string_buffer(96)

@@ -205,6 +205,90 @@ def calibrate_yolo_conf(model, device=None, frac=0.012, calib_frames=8, seed=99)
     return model
 
 
+class StreamingEngine:
+    """Throughput front end: `depth` batches in flight on one GPU.
+
+    Slot i owns a PoseEngine / YoloEngine (activations, parse workspace), a static input buffer, a device and a pinned
+    host record buffer, a HIP stream and -- once `capture()` has run -- ONE hipGraph of the whole step (pre-processing,
+    forward, parsing, record D2H copy).  `submit()` replays slot (ticket mod depth) on its stream and returns at once; the
+    latency-bound tail of a batch (head convolutions, pose assembly, the record copy) then overlaps with the convolutions
+    of the next batches (+35 % on one MI355X at depth 3).  Fill `input(slot)` (e.g. with a non_blocking
+    copy from pinned host memory issued on `stream(slot)`) before submitting; read `records(ticket)` / `host_records(ticket)`
+    after `wait(ticket)`.  A slot must be waited for before it is submitted again."""
+
+    def __init__(self, engine_cls=None, depth=3, frame_hw=(640, 480), frame_dtype=torch.float16, graph=True, **engine_kw):
+        engine_cls = PoseEngine if engine_cls is None else engine_cls
+        self.depth = max(1, int(depth))
+        engine_kw.setdefault("private_ctx", self.depth > 1)
+        self.engines = [engine_cls(**engine_kw) for _ in range(self.depth)]
+        e0 = self.engines[0]
+        self.device, self.max_batch = e0.device, e0.max_batch
+        item = e0.frames.shape[1]
+        self.inputs = [torch.zeros((self.max_batch,) + tuple(frame_hw), device=self.device, dtype=frame_dtype) for _ in range(self.depth)]
+        self.recs = [torch.empty((self.max_batch, item), device=self.device, dtype=torch.uint8) for _ in range(self.depth)]
+        self.host = [torch.empty((self.max_batch, item), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.events = [torch.cuda.Event() for _ in range(self.depth)]
+        self.graphs = [None] * self.depth
+        self._want_graph = bool(graph)
+        self._tickets = 0
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            st.wait_stream(cur)
+
+    def input(self, slot):
+        return self.inputs[slot % self.depth]
+
+    def stream(self, slot):
+        return self.streams[slot % self.depth]
+
+    def _body(self, s):
+        self.engines[s].predict(self.inputs[s], self.recs[s])
+        self.host[s].copy_(self.recs[s], non_blocking=True)
+
+    def capture(self):
+        """Warm every slot eagerly, then record its step as one hipGraph (same kernels, same arguments)."""
+        for s in range(self.depth):
+            with torch.cuda.stream(self.streams[s]):
+                self._body(s)
+                self._body(s)
+            torch.cuda.synchronize(self.device)
+            if self._want_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.streams[s]):
+                    self._body(s)
+                self.graphs[s] = g
+        torch.cuda.synchronize(self.device)
+
+    def submit(self, eager=False):
+        """Runs the next slot on its stream (asynchronous).  Returns the ticket."""
+        t = self._tickets
+        s = t % self.depth
+        with torch.cuda.stream(self.streams[s]):
+            if self.graphs[s] is not None and not eager:
+                self.graphs[s].replay()
+            else:
+                self._body(s)
+            self.events[s].record(self.streams[s])
+        self._tickets += 1
+        return t
+
+    def wait(self, ticket):
+        self.events[ticket % self.depth].synchronize()
+
+    def records(self, ticket):
+        return self.recs[ticket % self.depth]
+
+    def host_records(self, ticket):
+        return self.host[ticket % self.depth]
+
+    def join(self, stream=None):
+        """Makes `stream` (default: the current one) wait for everything submitted so far; no host synchronisation."""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        for st in self.streams:
+            stream.wait_stream(st)
+
+
 def wire_to_lists(wire):
     """pn_pose_wire records (numpy) -> the per-frame result-schema entries (float32 values widened to Python floats)."""
     out = {"human_pred_set_2d": [], "human_pred_set_3d": [], "human_pred_set_visibility": [], "human_pred_set_part_conf": []}

@@ -693,3 +693,25 @@ def test_end_to_end_metrics_match_reference_script_and_metric_code(gpu, golden, 
     for key, tol in (("pck2d", 1e-6), ("pck3d", 1e-6), ("ap2d", 1e-4), ("ap3d", 1e-4), ("err2d", 1e-6), ("err3d", 1e-4)):
         a, b = np.array(out[key], dtype=np.float64), np.array(s[key], dtype=np.float64)
         assert a.shape == b.shape and np.all((np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b))), (key, np.nanmax(np.abs(a - b)))
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_streaming_engine_tickets_and_records(gpu, graph):
+    """StreamingEngine (what bench.py drives): three batches in flight, every ticket's records equal what a plain
+    PoseEngine returns for that slot's input, graph replay or eager."""
+    from popnet_amd.pipeline import PoseEngine, StreamingEngine
+    se = StreamingEngine(PoseEngine, depth=3, graph=graph, precision="bf16", device=gpu, max_batch=4)
+    plain = PoseEngine(precision="bf16", device=gpu, max_batch=4)
+    batches = [torch.from_numpy(synth.synth_depth(4, 640, 480, seed=60 + i)).to(gpu) for i in range(3)]
+    want = [plain.predict(b).clone() for b in batches]
+    for i in range(3):
+        se.input(i).copy_(batches[i])
+    torch.cuda.synchronize()
+    se.capture()
+    tickets = [se.submit() for _ in range(9)]
+    for t in tickets[-3:]:
+        se.wait(t)
+        assert torch.equal(se.records(t), want[t % 3])
+        assert torch.equal(se.host_records(t), want[t % 3].cpu())
+    se.join()
+    torch.cuda.synchronize()
