@@ -26,6 +26,7 @@ def golden():
         script = json.load(open(os.path.join(GOLDEN, "script_eval_data.json")))
         script_yolo = json.load(open(os.path.join(GOLDEN, "script_eval_data_yolo.json")))
         script_metrics = json.load(open(os.path.join(GOLDEN, "script_metrics.json")))
+        script_metrics_yolo = json.load(open(os.path.join(GOLDEN, "script_metrics_yolo.json")))
     return G
 
 

@@ -520,7 +520,7 @@ def golden_metrics():
 
 
 # ---- F9: end-to-end metrics: the reference's evaluation script + its own metric code on a 12-frame synthetic split ----
-def golden_script_metrics():
+def golden_script_metrics(net="rtpose"):
     """12 synthetic frames through the reference evaluation script (same checkpoint recipe as F6), ground truth derived from
     its own predictions (jittered, some persons dropped) so that PCK / mAP are non-trivial, metrics by util/eval_pck.py and
     util/eval_mAP.py.  The GPU test feeds the same frames + labels to scripts/evaluate_mpreal.py and compares the metrics."""
@@ -530,6 +530,7 @@ def golden_script_metrics():
     import torch
     from popnet_amd import synth
     from lib.network.rtpose_light3d import rtpose_light3d
+    from lib.network.yolo_posenet import YoloPoseNet
     N = 12
     work = tempfile.mkdtemp(prefix="popnet_fake_ds_metrics_")
     img_dir = os.path.join(work, "depth_maps")
@@ -542,24 +543,36 @@ def golden_script_metrics():
         labels["f%02d.npy" % i] = [{"2d_joints": [[10.0 + j, 20.0] for j in range(15)], "3d_joints": [[0.0, 0.0, 3.0]] * 15}]
     ann = os.path.join(work, "labels.json")
     json.dump(labels, open(ann, "w"))
-    model = rtpose_light3d(15, 14, 2, input_dim=1).eval()
-    arrays = synth.fill_state_dict(model.state_dict(), seed=0)
-    model.load_state_dict(np_sd(arrays))
     x = np.stack([reference_preprocess(f, 6) for f in frames[:4]]).astype(np.float32)
-    shift = calibrated_heat_bias(model, x)
-    arrays["model2_2.12.bias"][:15] += shift
+    if net == "rtpose":
+        model = rtpose_light3d(15, 14, 2, input_dim=1).eval()
+        arrays = synth.fill_state_dict(model.state_dict(), seed=0)
+        model.load_state_dict(np_sd(arrays))
+        shift = calibrated_heat_bias(model, x)
+        arrays["model2_2.12.bias"][:15] += shift
+        script, a_ann, a_img = "evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py", "--annotations", "--image-dir"
+    else:
+        model = YoloPoseNet(15, input_dim=1).eval()
+        arrays = synth.fill_state_dict(model.state_dict(), seed=1)
+        model.load_state_dict(np_sd(arrays))
+        shift = np.float32(yolo_conf_shift(model, x))
+        arrays["model2_4.0.weight"][[4, 54]] -= shift
+        script, a_ann, a_img = "evaluation_yolo_posenet_kdh3d_mpreal.py", "--val-annotations", "--val-image-dir"
     ckpt = os.path.join(work, "ckpt.pth")
     torch.save({"module." + k: torch.from_numpy(v) for k, v in arrays.items()}, ckpt)
     outdir = os.path.join(work, "out")
     argv, cwd = sys.argv, os.getcwd()
     try:
         os.chdir(os.path.join(TPM, "evaluate"))
-        sys.argv = ["eval", "--annotations", ann, "--image-dir", img_dir, "--w-org", "480", "--h-org", "640",
+        sys.argv = ["eval", a_ann, ann, a_img, img_dir, "--w-org", "480", "--h-org", "640",
                     "--batch-size", "4", "--weight", ckpt, "--output-dir", outdir]
         import matplotlib
         matplotlib.use("Agg")
         with contextlib.redirect_stdout(io.StringIO()):
-            runpy.run_path(os.path.join(TPM, "evaluate", "evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py"), run_name="__main__")
+            try:
+                runpy.run_path(os.path.join(TPM, "evaluate", script), run_name="__main__")
+            except Exception as e:      # the scripts' own metric tail may trip after eval_data.json has been written
+                print("F9 (%s): script raised after the dump: %r" % (net, e), file=sys.stderr)
     finally:
         sys.argv = argv
         os.chdir(cwd)
@@ -588,12 +601,13 @@ def golden_script_metrics():
         d3, k3 = RP.eval_human_dataset_3d(copy.deepcopy(p2), copy.deepcopy(g2), copy.deepcopy(p3), copy.deepcopy(g3), num_joints=15, dist_th=0.1, iou_th=0.5)
         a2 = RA.eval_ap_mpii_v2(copy.deepcopy(p2), copy.deepcopy(pc), copy.deepcopy(g2), gt_visibility_set=[], head_id=0, neck_id=1, joint_names=names, thresh=0.5)
         a3 = RA.eval_ap_3D(copy.deepcopy(p3), copy.deepcopy(pc), copy.deepcopy(g3), gt_visibility_set=[], joint_names=names, thresh=0.1)
-    out = {"depth_seed": 79, "weight_seed": 0, "n_frames": N, "heat_bias_shift": shift.tolist(), "gt_2d": g2, "gt_3d": g3,
+    out = {"depth_seed": 79, "weight_seed": 0 if net == "rtpose" else 1, "n_frames": N, "gt_2d": g2, "gt_3d": g3,
+           ("heat_bias_shift" if net == "rtpose" else "conf_weight_shift"): np.asarray(shift).tolist(),
            "persons_per_frame": [len(f) for f in p2],
            "pck2d": [float(v) for v in k2], "err2d": [float(v) for v in d2], "pck3d": [float(v) for v in k3], "err3d": [float(v) for v in d3],
            "ap2d": np.asarray(a2).tolist(), "ap3d": np.asarray(a3).tolist()}
-    json.dump(out, open(os.path.join(HERE, "script_metrics.json"), "w"))
-    print("F9: persons/frame", out["persons_per_frame"], "GT/frame", [len(f) for f in g2])
+    json.dump(out, open(os.path.join(HERE, "script_metrics.json" if net == "rtpose" else "script_metrics_yolo.json"), "w"))
+    print("F9 (%s): persons/frame" % net, out["persons_per_frame"], "GT/frame", [len(f) for f in g2])
     print("F9: PCK2D %.3f PCK3D %.3f AP2D %.2f AP3D %.2f" % (np.nanmean(k2), np.nanmean(k3), a2[-1], a3[-1]))
 
 
@@ -601,9 +615,10 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate golden vectors"
     install_shims()
     import popnet_amd  # noqa: F401
-    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics"]
+    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo"]
     fns = {"keys": golden_state_dicts, "forward": golden_forward, "parse": golden_parse, "yolo": golden_yolo,
            "pafprocess": golden_pafprocess, "script": golden_script,
-           "script_yolo": golden_script_yolo, "metrics": golden_metrics, "script_metrics": golden_script_metrics}
+           "script_yolo": golden_script_yolo, "metrics": golden_metrics, "script_metrics": golden_script_metrics,
+           "script_metrics_yolo": lambda: golden_script_metrics("yolo")}
     for w in which:
         fns[w]()
