@@ -7,8 +7,8 @@ int pn_launch_conv3_part2(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) 
 }
 
 // LDS bytes of one block: NBUF piece-major halo images + the dump slot of the branch-free DMA
-size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf, int pt) {
-    const int hr = (pt * 4 / 7) * WP + ks - 1 + (((ks - 1) & 1) ? 1 : 0);
+size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf, int rpg) {
+    const int hr = rpg * WP + ks - 1 + (((ks - 1) & 1) ? 1 : 0);
     return (size_t)8 * hr * 32 * 16 * nbuf + 1024;
 }
 

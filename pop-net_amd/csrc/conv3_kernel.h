@@ -36,12 +36,13 @@ __device__ __forceinline__ void pn_glds16(gcptr src, unsigned lds_dst) {
 // PT = pixel tiles of 16 per wave: 7 (112 pixels = 4 rows of a 28-column strip, 56 accumulator VGPRs, 4 waves / SIMD) or
 // 14 (224 pixels = 8 rows, 112 accumulator VGPRs, 2 waves / SIMD: half the weight bytes per MFMA, for Cin = 64 layers
 // on large maps, whose 224-pixel tiles otherwise stream their whole weight slice twice).
-template <int KS, int WC, int WP, int NBUF, int PT>
+// RPG = output rows per wave group kept in the halo image: 4 for 24..30-column strips (4 x 28 = 112 pixels), 8 for
+// narrow maps (8 x 14 = 112: the 14x14 layers of YoloPoseNet), 8 as well for PT = 14.
+template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7>
 __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CONV3_OCC)) void conv3_kernel(const ConvProblem *__restrict__ probs) {
     typedef __bf16 T;
     typedef Elem<PN_PREC_BF16>::Frag Frag;
     constexpr int CT = 2, NT = WC * WP * 64, NW = WC * WP;
-    constexpr int RPG = PT * 4 / 7;                    // output rows of a 28-column strip per wave group
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int PITCH = 32;                          // halo pixels per LDS row
     constexpr int HR = RPG * WP + KS - 1 + ((KS - 1) & 1 ? 1 : 0);   // halo rows (even: one DMA fills two rows)
@@ -305,9 +306,9 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     PN_STAMP_AT(12);
 }
 
-template <int KS, int WC, int WP, int NBUF, int PT = 7>
+template <int KS, int WC, int WP, int NBUF, int PT = 7, int RPG = PT * 4 / 7>
 static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
-    auto kern = conv3_kernel<KS, WC, WP, NBUF, PT>;
+    auto kern = conv3_kernel<KS, WC, WP, NBUF, PT, RPG>;
     if (L.lds_bytes > 48 * 1024) {
         static size_t configured = 0;   // per instantiation
         if (configured < L.lds_bytes) {
@@ -321,9 +322,11 @@ static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream
     return PN_OK;
 }
 #define PN3_CASE(KS, WC, WP, NB) \
-    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
 #define PN3_CASE_PT(KS, WC, WP, NB, PT_) \
-    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == PT_) return conv3_launch_one<KS, WC, WP, NB, PT_>(ctx, L, stream);
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == PT_ && L.rpg == PT_ * 4 / 7) return conv3_launch_one<KS, WC, WP, NB, PT_>(ctx, L, stream);
+#define PN3_CASE_RPG(KS, WC, WP, NB, RPG_) \
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == RPG_) return conv3_launch_one<KS, WC, WP, NB, 7, RPG_>(ctx, L, stream);
 int pn_launch_conv3_part0(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 int pn_launch_conv3_part1(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 int pn_launch_conv3_part2(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);

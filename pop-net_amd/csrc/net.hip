@@ -47,7 +47,7 @@ struct ConvSpec {
     int cout = 0;
     // derived
     int cfg = 0, pitch = 0, R = 0, Wt = 0, cin_chunks = 0;
-    int kern = 0, wc = 0, wp = 0, nbuf = 0, pt = 7;   // kern 3: conv3_kernel<ks, wc, wp, nbuf, pt> (bf16, stride 1, strip tiles)
+    int kern = 0, wc = 0, wp = 0, nbuf = 0, pt = 7, rpg = 4;   // kern 3: conv3_kernel<ks, wc, wp, nbuf, pt, rpg> (bf16, stride 1, strip tiles)
     int wc_min = 0, nbuf_min = 0;             // set by harmonize_level: share the launch of a wider sibling conv
     void *wpack = nullptr;
     float *bias = nullptr;
@@ -194,20 +194,25 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     {   // bf16 stride-1 layers run conv3_kernel (conv3_kernel.h) when the map splits into column strips (<= 30 wide: the
         // halo row is 32 pixels) whose 4-row tiles fill >= 75 % of a wave group's 112 pixel slots
         const Buf &ib0 = n->bufs[cs.in_buf];
-        int segs = 0, wt = 0, rows = 0;
+        int segs = 0, wt = 0, rows = 0, rpg = 4;
         double best = 0;
         for (int sg = (ib0.W + 29) / 30; sg <= (ib0.W + 15) / 16; ++sg) {
-            const int w = (ib0.W + sg - 1) / sg, r = std::min(std::min(ib0.H, 4), 112 / w);
-            const double util = r * ((double)ib0.W / sg) / 112.0;
-            if (util > best + 1e-9) { best = util; segs = sg; wt = w; rows = r; }
+            const int w = (ib0.W + sg - 1) / sg;
+            for (int g : {4, 8}) {                       // rows per wave group kept in LDS (8: narrow maps only, 3x3 / 128-cout blocks)
+                if (g == 8 && !(w <= 14 && ks == 3 && cout > 64 && getenv("POPNET_CONV3_RPG8"))) continue;   // measured slower than the generic kernel on 14x14 maps (profiles/README.md v15)
+                const int r = std::min(std::min(ib0.H, g), 112 / w);
+                const double util = r * ((double)ib0.W / sg) / 112.0;
+                if (util > best + 1e-9) { best = util; segs = sg; wt = w; rows = r; rpg = g; }
+            }
         }
         if (n->prec == PN_PREC_BF16 && cs.stride == 1 && (ks == 3 || ks == 1) && best >= 0.75 && cout > 32 && !getenv("POPNET_NO_CONV3")) {
             cs.kern = 3;
             cs.wc = std::max(cout > 64 ? 4 : (cout > 32 ? 2 : 1), cs.wc_min);
             const long tiles112 = (long)n->max_batch * ((ib0.H + rows - 1) / rows) * segs;   // strip tiles of one wave group
-            cs.wp = (cs.wc == 2 && rows == 4 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;   // big maps: 8-row tiles, 256 threads
-            if (cs.wp == 2 && ks == 3 && cs.cin_chunks == 1 && getenv("POPNET_CONV3_PT14")) { cs.wp = 1; cs.pt = 14; }   // 8 rows per WAVE: half the weight bytes
-            const int hr = 4 * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
+            cs.wp = (cs.wc == 2 && rows == 4 && rpg == 4 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;   // big maps: 8-row tiles, 256 threads
+            cs.rpg = rpg;
+            if (cs.wp == 2 && ks == 3 && cs.cin_chunks == 1 && getenv("POPNET_CONV3_PT14")) { cs.wp = 1; cs.pt = 14; cs.rpg = 8; }   // 8 rows per WAVE: half the weight bytes
+            const int hr = rpg * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
             // single halo image (4 waves / SIMD) beats the double-buffered variant (3 waves / SIMD) on every level
             // of both networks (profiles/README.md, r01 v8); POPNET_CONV3_NBUF2=1 selects the latter for experiments
             cs.nbuf = ((cs.cin_chunks > 1 || cs.nbuf_min == 2) && ks == 3 && ngw <= 18 && getenv("POPNET_CONV3_NBUF2")) ? 2 : 1;
@@ -333,7 +338,7 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
             if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
-                (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt) : b.cfg == a.cfg)) {
+                (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg)) {
                 st.conv_ids.push_back(ids[j]);
                 used[j] = true;
             }
@@ -577,8 +582,8 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.nprob = (int)st.host_probs.size();
         st.launch.max_blocks = max_blocks;
         st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R) * (two_bufs ? 2 : 1);
-        st.launch.kern = c0.kern; st.launch.wc = c0.wc; st.launch.wp = c0.wp; st.launch.nbuf = c0.nbuf; st.launch.pt = c0.pt;
-        if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf, c0.pt);
+        st.launch.kern = c0.kern; st.launch.wc = c0.wc; st.launch.wp = c0.wp; st.launch.nbuf = c0.nbuf; st.launch.pt = c0.pt; st.launch.rpg = c0.rpg;
+        if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf, c0.rpg);
         st.launch.probs_dev = st.dev_probs;
         PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),
                                             hipMemcpyHostToDevice, stream));
@@ -614,7 +619,7 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
                 for (int id : st.conv_ids) pr->flops += n->convs[id].flops * B;
                 char lb[96];
                 const ConvLaunch &cl = st.launch;
-                if (cl.kern == 3) snprintf(lb, sizeof lb, "conv3_kernel<%d, %d, %d, %d, %d>", cl.ks, cl.wc, cl.wp, cl.nbuf, cl.pt);
+                if (cl.kern == 3) snprintf(lb, sizeof lb, "conv3_kernel<%d, %d, %d, %d, %d, %d>", cl.ks, cl.wc, cl.wp, cl.nbuf, cl.pt, cl.rpg);
                 else snprintf(lb, sizeof lb, "conv_mfma_kernel<%d, %d, %d, %d, %d>", cl.prec, cl.ks, cl.stride, cl.pitch, cl.cfg);
                 pr->label = lb;
             }

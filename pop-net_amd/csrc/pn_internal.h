@@ -92,7 +92,7 @@ struct ConvLaunch {
     int stride;    // 1 or 2
     int pitch;     // LDS halo row pitch in pixels (multiple of 8, >= halo columns)
     int cfg;       // pn_conv_cfg
-    int kern = 0, wc = 0, wp = 0, nbuf = 0, pt = 7;   // kern 3: conv3_kernel<ks, wc, wp, nbuf, pt>
+    int kern = 0, wc = 0, wp = 0, nbuf = 0, pt = 7, rpg = 4;   // kern 3: conv3_kernel<ks, wc, wp, nbuf, pt, rpg>
     int nprob;
     int max_blocks;          // max nblocks over the group
     size_t lds_bytes;
@@ -100,7 +100,7 @@ struct ConvLaunch {
 };
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 int pn_launch_conv3(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);     // conv3_inst_*.hip
-size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf, int pt = 7);
+size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf, int rpg = 4);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
 int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 0 = no limit (direct staging)
 

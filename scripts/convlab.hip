@@ -214,7 +214,7 @@ int main(int argc, char **argv) {
         printf("v3 kernel: cfg %d (WC %d WP %d) NBUF %d R %d Wt %d blocks %d lds %zu\n", cfg, WC, WP, nbuf, R, Wt, nblocks, lds);
         auto launch = [&]() {
             dim3 grid(gridx, gridy);
-#define LAB3(KS_, WC_, WP_, NB_) if (ks == KS_ && WC == WC_ && WP == WP_ && nbuf == NB_) { auto kern = conv3_kernel<KS_, WC_, WP_, NB_, 7>; \
+#define LAB3(KS_, WC_, WP_, NB_) if (ks == KS_ && WC == WC_ && WP == WP_ && nbuf == NB_) { auto kern = conv3_kernel<KS_, WC_, WP_, NB_, 7, 4>; \
                 if (lds > 48 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL(kern, grid, dim3(WC_ * WP_ * 64), lds, 0, dP); return; }
             LAB3(3, 4, 1, 1) LAB3(3, 2, 2, 1) LAB3(3, 2, 1, 1) LAB3(3, 4, 1, 2) LAB3(3, 2, 2, 2) LAB3(3, 2, 1, 2) LAB3(3, 4, 2, 1)
