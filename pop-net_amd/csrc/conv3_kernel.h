@@ -42,7 +42,7 @@ template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7>
 __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CONV3_OCC)) void conv3_kernel(const ConvProblem *__restrict__ probs) {
     typedef __bf16 T;
     typedef Elem<PN_PREC_BF16>::Frag Frag;
-    constexpr int CT = 2, NT = WC * WP * 64, NW = WC * WP;
+    constexpr int CT = 2, NW = WC * WP;
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int PITCH = 32;                          // halo pixels per LDS row
     constexpr int HR = RPG * WP + KS - 1 + ((KS - 1) & 1 ? 1 : 0);   // halo rows (even: one DMA fills two rows)
