@@ -175,12 +175,20 @@ def main():
     torch.cuda.synchronize()
     L.pn_net_profile_begin(engine.net)                           # only slot 0's net records events: its launches alone
     t1 = time.perf_counter()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
     with torch.cuda.stream(streams[0]):
         for k in range(K):
-            engine.predict(se.input(0), se.records(0))
+            nb = engine.preprocess(se.input(0))
+            engine.forward(nb)
+            ev[k][0].record()
+            engine.parse(nb, se.records(0))                  # post-processing kernels of this step, bracketed on their stream
+            ev[k][1].record()
             se.host_records(0).copy_(se.records(0), non_blocking=True)
+            ev[k][2].record()
     torch.cuda.synchronize()
     elapsed_profiled = time.perf_counter() - t1
+    post_ms = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
+    d2h_ms = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
     conv_ms, other_ms, conv_flops = C.c_double(), C.c_double(), C.c_double()
     conv_n, other_n = C.c_int64(), C.c_int64()
     engine.ctx.check(L.pn_net_profile_end(engine.net, C.byref(conv_ms), C.byref(conv_n), C.byref(conv_flops),
@@ -203,6 +211,8 @@ def main():
         total_frames = world * K * BATCH
         achieved = conv_flops.value / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+        # network outputs read + records written per frame
+        post_bytes = BATCH * ((185024 if args.net == "rtpose" else 100 * 14 * 14 * 4) + item)
         dom = kernels[0] if kernels else {"kernel": "none", "us_per_step": 0.0, "avg_launch_us": 0.0, "tflops": 0.0, "flops_per_launch": 0.0, "launches_per_step": 0}
         traffic = None                                          # HBM bytes per launch of the dominant kernel (separate rocprofv3 --pmc passes)
         pmc = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
@@ -230,6 +240,11 @@ def main():
                                         "ms_per_step": round(conv_ms.value / K, 4), "tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
                                         "stem_pool_ms_per_step": round(other_ms.value / K, 4), "by_kernel": kernels},
                          "measured": "HIP events around every conv launch on the launch stream, the same %d steps re-run eagerly on one engine right after the timed region (%.4f ms/step with events)" % (K, elapsed_profiled / K * 1e3)},
+            "postproc": {"bound": "hbm", "kernels": "pose parsing (NMS + refine, limb scoring + matching, assembly + read-out)" if args.net == "rtpose" else "box decode + NMS + skeleton read-out",
+                         "algorithmic_bytes_per_step": post_bytes, "us_per_step": round(post_ms * 1e3, 2),
+                         "achieved": round(post_bytes / (post_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(post_bytes / (post_ms * 1e-3) / 8e12, 5), "record_d2h_us_per_step": round(d2h_ms * 1e3, 2),
+                         "note": "latency-bound: 32 small frames per step; hidden behind the next batch by the StreamingEngine"},
             "frame_stats": {"mean_peaks": round(float(recs['n_peaks' if args.net == "rtpose" else 'n_candidates'].mean()), 2),
                             "mean_persons": round(float(recs['n_persons' if args.net == "rtpose" else 'n_det'].mean()), 3),
                             "overflow_frames": int((recs['status'] != 0).sum()),
