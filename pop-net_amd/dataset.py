@@ -113,6 +113,57 @@ def run_sweep(engine, frames, batch_size=32, rank=0, world=1, drop_last=False, g
     return local.cpu().numpy().view(dtype).reshape(-1)
 
 
+def run_sweep_streaming(se, frames, batch_size=32, rank=0, world=1, drop_last=False, group=None):
+    """Same result as run_sweep, through a pipeline.StreamingEngine: batch k+1 is read from disk, pinned and copied to
+    the device (on its slot's stream) while batches k, k-1 are still being computed; a slot's records are collected right
+    before the slot is reused."""
+    import torch
+    from .pipeline import gather_records, shard_indices
+    n = len(frames)
+    if drop_last:
+        n -= n % (batch_size * world)
+    mine = shard_indices(n, rank, world)
+    item = se.recs[0].shape[1]
+    bs = min(batch_size, se.max_batch)
+    local = torch.empty((len(mine), item), dtype=torch.uint8, device=se.device)
+    pending = {}                                   # slot -> (ticket, offset, count)
+    pinned = [None] * se.depth
+
+    def collect(slot):
+        t, off, cnt = pending.pop(slot)
+        se.wait(t)
+        with torch.cuda.stream(se.stream(slot)):
+            local[off:off + cnt].copy_(se.records(t)[:cnt], non_blocking=True)
+
+    done = 0
+    for chunk, host in frames.batches(mine, bs):
+        slot = se._tickets % se.depth
+        if slot in pending:
+            collect(slot)
+        buf = se.input(slot)
+        if tuple(host.shape[1:]) != tuple(buf.shape[1:]) or torch.from_numpy(host[:1]).dtype != buf.dtype:
+            raise _lib.PopnetError("frames are %s %s, the StreamingEngine was built for %s %s" % (host.shape[1:], host.dtype, tuple(buf.shape[1:]), buf.dtype))
+        if pinned[slot] is None:
+            pinned[slot] = torch.empty((se.max_batch,) + tuple(host.shape[1:]), dtype=buf.dtype).pin_memory()
+        se.stream(slot).synchronize()              # the previous H2D copy out of this pinned buffer has finished
+        pinned[slot][:len(chunk)].copy_(torch.from_numpy(host))
+        with torch.cuda.stream(se.stream(slot)):
+            buf[:len(chunk)].copy_(pinned[slot][:len(chunk)], non_blocking=True)
+            if len(chunk) < se.max_batch:
+                buf[len(chunk):].zero_()          # a ragged tail batch runs full-size; its surplus records are dropped
+        t = se.submit()
+        pending[slot] = (t, done, len(chunk))
+        done += len(chunk)
+    for slot in list(pending):
+        collect(slot)
+    se.join()
+    torch.cuda.synchronize(se.device)
+    if world > 1:
+        local = gather_records(local, n, rank, world, group)
+    dtype = _lib.POSE_FRAME_DTYPE if item == _lib.POSE_FRAME_DTYPE.itemsize else _lib.YOLO_FRAME_DTYPE
+    return local.cpu().numpy().view(dtype).reshape(-1)
+
+
 def eval_data_from_records(recs, frames):
     """The eval_data.json dictionary for a finished sweep (predictions from the records, ground truth from the labels)."""
     data = pose_records_to_lists(recs) if recs.dtype == _lib.POSE_FRAME_DTYPE else yolo_records_to_lists(recs)

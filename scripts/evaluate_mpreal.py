@@ -32,6 +32,7 @@ def main(argv=None):
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="fp32 = parity mode (1e-3 m), bf16 = throughput mode")
     ap.add_argument("--drop-last", action="store_true", help="skip the tail like the reference's drop_last=True loader")
     ap.add_argument("--no-metrics", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (StreamingEngine); 1 = plain sequential engine")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -46,15 +47,21 @@ def main(argv=None):
 
     import popnet_amd  # noqa: F401
     from popnet_amd import dataset, metrics
-    from popnet_amd.pipeline import PoseEngine, YoloEngine
+    from popnet_amd.pipeline import PoseEngine, StreamingEngine, YoloEngine
 
     frames = dataset.MP3DHPFrames(args.image_dir, args.annotations)
     sd = torch.load(args.weight, map_location="cpu")
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
     Engine = PoseEngine if args.net == "rtpose" else YoloEngine
-    engine = Engine(precision=args.precision, state_dict=sd, device=dev, max_batch=args.batch_size, input_size=args.input_size,
-                    w_org=args.w_org, h_org=args.h_org, intrinsics=frames.intrinsics)
-    recs = dataset.run_sweep(engine, frames, args.batch_size, rank, world, args.drop_last)
+    kw = dict(precision=args.precision, state_dict=sd, device=dev, max_batch=args.batch_size, input_size=args.input_size,
+              w_org=args.w_org, h_org=args.h_org, intrinsics=frames.intrinsics)
+    if args.pipeline > 1 and len(frames):
+        f0 = frames.load(0)
+        se = StreamingEngine(Engine, depth=args.pipeline, frame_hw=f0.shape, frame_dtype=torch.from_numpy(f0[:1]).dtype, **kw)
+        se.capture()
+        recs = dataset.run_sweep_streaming(se, frames, args.batch_size, rank, world, args.drop_last)
+    else:
+        recs = dataset.run_sweep(Engine(**kw), frames, args.batch_size, rank, world, args.drop_last)
     out = None
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)

@@ -748,3 +748,23 @@ def test_parse_fuzz_noisy_planted_maps_vs_oracle(gpu, noise, drop, sigma):
             assert np.array_equal(fr["joints_3d"][:n], np.array(rec["humans_3d"]))
             assert np.array_equal(fr["part_conf"][:n], np.array(rec["conf"]))
     assert checked >= 12
+
+
+def test_streaming_sweep_equals_sequential_sweep(gpu, tmp_path):
+    """dataset.run_sweep_streaming (3 batches in flight, ragged tail batch) returns exactly the records of the plain
+    sequential sweep, in frame order."""
+    import json
+    from popnet_amd import dataset
+    from popnet_amd.pipeline import PoseEngine, StreamingEngine
+    frames = synth.synth_depth(11, 640, 480, seed=91)
+    labels = {"intrinsics": {"fx": 504.1189880371094, "fy": 504.042724609375, "cx": 231.7421875, "cy": 320.62640380859375}}
+    for i in range(11):
+        np.save(tmp_path / ("g%02d.npy" % i), frames[i])
+        labels["g%02d.npy" % i] = []
+    json.dump(labels, open(tmp_path / "labels.json", "w"))
+    fr = dataset.MP3DHPFrames(str(tmp_path), str(tmp_path / "labels.json"))
+    seq = dataset.run_sweep(PoseEngine(precision="bf16", device=gpu, max_batch=4), fr, 4)
+    se = StreamingEngine(PoseEngine, depth=3, frame_hw=(640, 480), precision="bf16", device=gpu, max_batch=4)
+    se.capture()
+    got = dataset.run_sweep_streaming(se, fr, 4)
+    assert len(got) == 11 and got.tobytes() == seq.tobytes()
