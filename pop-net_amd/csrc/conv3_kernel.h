@@ -7,13 +7,16 @@
 // resnet.py:27-56).  What differs, and why (profiles/README.md, round-1 timeline stamps):
 //   * 4 waves per SIMD instead of 2 (<= 128 VGPRs): a block's fixed latencies (first halo fetch,
 //     chunk hand-over, epilogue burst) overlap with the MFMAs of the three other blocks of the CU.
-//   * LDS halo image is PIECE-MAJOR: [8 channel pieces of 16 B][halo row][32 px][16 B].  The 16
-//     lanes one ds_read_b128 phase serves read 16 consecutive 16-B entries (conflict-free with no
-//     XOR swizzle), so tap (ky,kx) and the 32-channel half are IMMEDIATE offsets of one address
-//     register per pixel tile (7 VGPRs instead of 42).
-//   * The halo is filled by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write.
-//     One wave instruction fills 2 halo rows of one piece plane; out-of-image pixels read a zero
-//     page that lives at the end of every activation buffer (ConvProblem::in_zero_off).
+//   * LDS halo image is HALF-MAJOR: [2 halves of 32 channels][halo row][32 px][4 pieces x 16 B].  Tap (ky,kx) and
+//     the 32-channel half are IMMEDIATE offsets of one address register per pixel tile (7 VGPRs instead of the 42 of
+//     the pixel-major + XOR layout), and no swizzle is needed: the 8 pixels one lane quarter reads per ds_read_b128
+//     phase fall on 4 bank groups, a 2-way conflict (8 instead of 4 LDS cycles per read; LDS has the slack -- removing
+//     every conflict in a timing experiment bought 2 %).  The first version was piece-major ([8 pieces][row][px][16 B],
+//     conflict-free reads) but its fill gathered 64 pixels x 16 B per DMA instruction -- 64 requests to the texture
+//     addresser; half-major fills 16 pixels x 64 contiguous bytes per instruction (4 adjacent lanes = one 64-B segment):
+//     -8 % on the 112x112 layers, -4 % on the stage levels, +5 % end to end (profiles/README.md v16).
+//   * The halo is filled by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write; out-of-image pixels
+//     read a zero page that lives at the end of every activation buffer (ConvProblem::in_zero_off).
 //   * One LDS image per block (24.5 KB for a 4-row strip tile): the chunk hand-over stalls this
 //     block only; occupancy hides it.
 //   * Weights: global -> VGPR fragments through a 3-slot queue (2 k-steps ahead is enough at 4
@@ -23,6 +26,9 @@
 
 #ifndef PN_CONV3_OCC
 #define PN_CONV3_OCC 4
+#endif
+#ifndef PN_CONV3_PIECEMAJOR
+#define PN_CONV3_HALFMAJOR 1      // LDS halo layout, see the header comment; -DPN_CONV3_PIECEMAJOR selects the first layout (experiments)
 #endif
 
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_dst, lds_dst + 1024).
@@ -119,17 +125,34 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     auto stage_one = [&](int chunk, int j, int bufoff, bool live) {   // j-th DMA instruction of this wave for `chunk`
         const int n = wave * NGW + j;                    // wave-uniform
         const bool on = live && n < NG;
+#ifdef PN_CONV3_HALFMAJOR
+        // half-major image [2 halves][halo row][32 px][4 pieces x 16 B]: one instruction = 16 pixels x 64 contiguous bytes
+        // (4 adjacent lanes = one 64-B segment of a pixel line) instead of 64 pixels x 16 B
+        const int hh = n / (2 * HR), rr = (n - hh * 2 * HR) >> 1, gg = n & 1;
+        const int px = gg * 16 + (lane >> 2);
+        const int iy = iy0 + rr;
+        const bool inb = (int)on & (int)(px < HC) & (int)((unsigned)(ix0 + px) < (unsigned)P.W) & (int)((unsigned)iy < (unsigned)Hin);
+        unsigned off = (unsigned)(iy * row_b + (ix0 + px) * col_b + hh * 64 + (lane & 3) * 16);
+        const int pc = 0, i = 0;
+        const int dst_hm = hh * (IMG / 2) + (rr * PITCH + gg * 16) * 64;
+#else
         const int pc = n / (HR / 2), i = n - pc * (HR / 2);
         const int iy = iy0 + 2 * i + hrow;
         const bool inb = (int)on & (int)col_ok & (int)((unsigned)iy < (unsigned)Hin);
         unsigned off = (unsigned)(iy * row_b + pc * 16) + coloff;
+        const int dst_hm = 0;
+#endif
 #ifdef PN_CONV3_FAKE_LINDMA   // timing experiment (wrong results): each DMA instruction reads 1 KB of consecutive bytes
         off = (unsigned)(min(max(iy0 + 2 * i, 0), Hin - 2) * row_b + max(ix0, 0) * col_b) + lane * 16;
 #endif
         asm volatile("" : "+v"(off));                    // materialise: the select below must stay a v_cndmask, not a branch
         const unsigned zrel = zero_rel - (unsigned)(chunk * 128);
         pn_glds16(img + chunk * 128 + (inb ? off : zrel),
-                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + pc * PS + i * (2 * PITCH * 16) : NBUF * IMG));
+#ifdef PN_CONV3_HALFMAJOR
+                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + dst_hm : NBUF * IMG));
+#else
+                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + pc * PS + i * (2 * PITCH * 16) + dst_hm : NBUF * IMG));
+#endif
     };
     auto stage = [&](int chunk, int bufoff) {
 #pragma unroll
@@ -145,7 +168,11 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
         int s = slot < npix ? slot : 0;
         int ry = (int)(((float)s + 0.5f) * inv_wc);
         int rx = s - ry * Wc;
+#ifdef PN_CONV3_HALFMAJOR
+        baddr[pt] = q * 16 + (ry * PITCH + rx) * 64;
+#else
         baddr[pt] = q * PS + (ry * PITCH + rx) * 16;
+#endif
 #ifdef PN_CONV3_FAKE_NOWRAP   // timing experiment only (wrong results): every pixel tile reads 16 consecutive entries
         baddr[pt] = q * PS + (pt * 16 + c) * 16;
 #endif
@@ -174,7 +201,11 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
             if (NBUF == 2 && more) stage(chunk + 1, nxt);
         } else {
         // item j = (k-step s = half * KK + tap, pixel tile pt)
+#ifdef PN_CONV3_HALFMAJOR
+#define PN3_OFF(j) ((((j) / PT) / KK) * (IMG / 2) + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 64)
+#else
 #define PN3_OFF(j) ((((j) / PT) / KK) * 4 * PS + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 16)
+#endif
         Frag bq[DB];
 #pragma unroll
         for (int j = 0; j < DB - 1; ++j) bq[j] = read_b_frag<PN_PREC_BF16>(sm + PN3_OFF(j), baddr[j % PT]);
