@@ -147,11 +147,13 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
 #endif
         asm volatile("" : "+v"(off));                    // materialise: the select below must stay a v_cndmask, not a branch
         const unsigned zrel = zero_rel - (unsigned)(chunk * 128);
+#ifndef PN_CONV3_FAKE_NODMA                               // timing experiment (wrong results): no halo fetch at all
         pn_glds16(img + chunk * 128 + (inb ? off : zrel),
 #ifdef PN_CONV3_HALFMAJOR
                   (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + dst_hm : NBUF * IMG));
 #else
                   (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + pc * PS + i * (2 * PITCH * 16) + dst_hm : NBUF * IMG));
+#endif
 #endif
     };
     auto stage = [&](int chunk, int bufoff) {
