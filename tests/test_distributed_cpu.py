@@ -39,3 +39,58 @@ def test_gather_records_world2_gloo():
         port = 29500 + (os.getpid() % 1000) + n_frames % 7
         mp.spawn(_worker, args=(2, n_frames, port, ret), nprocs=2, join=True)
         assert ret[0] and ret[1]
+
+
+class _FakeEngine:
+    """Stands in for PoseEngine on the CPU: a 'record' of a frame is 64 bytes derived from the frame's content, so the
+    sharded sweep can be checked end to end (dataset listing -> shard -> batches -> gather -> global order) without a GPU."""
+    def __init__(self, max_batch):
+        self.device, self.max_batch = torch.device("cpu"), max_batch
+        self.frames = torch.empty((max_batch, 64), dtype=torch.uint8)
+
+    def predict(self, depth):
+        tag = depth.float().reshape(depth.shape[0], -1)[:, 0].round().to(torch.int64)     # the frame stores its own index
+        out = torch.zeros((depth.shape[0], 64), dtype=torch.uint8)
+        out[:, 0] = (tag & 255).to(torch.uint8)
+        out[:, 1] = ((tag >> 8) & 255).to(torch.uint8)
+        return out
+
+
+def _sweep_worker(rank, world, root_dir, n_frames, port, ret):
+    sys.path.insert(0, ROOT)
+    import popnet_amd  # noqa: F401
+    from popnet_amd import _lib, dataset
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fr = dataset.MP3DHPFrames(root_dir, os.path.join(root_dir, "labels.json"))
+    item = 64
+    # run_sweep reinterprets the gathered bytes with the record dtype: patch the lookup to a 64-byte dtype for the fake
+    old = _lib.YOLO_FRAME_DTYPE
+    _lib.YOLO_FRAME_DTYPE = np.dtype([("b", np.uint8, (item,))])
+    try:
+        recs = dataset.run_sweep(_FakeEngine(3), fr, batch_size=3, rank=rank, world=world)
+    finally:
+        _lib.YOLO_FRAME_DTYPE = old
+    ok = len(recs) == n_frames
+    for i in range(n_frames):
+        ok &= int(recs[i]["b"][0]) == (i & 255) and int(recs[i]["b"][1]) == (i >> 8)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sharded_dataset_sweep_world2_gloo(tmp_path):
+    """dataset.run_sweep with two ranks: every rank ends up with all records in label-file order (ragged last batches)."""
+    import json
+    n_frames = 11
+    labels = {"intrinsics": {"fx": 1, "fy": 1, "cx": 0, "cy": 0}}
+    for i in range(n_frames):
+        name = "z%02d.npy" % (n_frames - i)                      # names NOT in sorted order: dict order must win
+        np.save(tmp_path / name, np.full((4, 4), float(i), np.float32))
+        labels[name] = []
+    json.dump(labels, open(tmp_path / "labels.json", "w"))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_sweep_worker, args=(2, str(tmp_path), n_frames, port, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
