@@ -27,6 +27,7 @@
 #ifndef PN_CONV3_OCC
 #define PN_CONV3_OCC 4
 #endif
+// -DPN_CONV3_NT_STORE: output tiles leave with the nt hint (experiment v21: faster alone, slower in the network, where the next layer re-reads them)
 #ifndef PN_CONV3_PIECEMAJOR
 #define PN_CONV3_HALFMAJOR 1      // LDS halo layout, see the header comment; -DPN_CONV3_PIECEMAJOR selects the first layout (experiments)
 #endif
@@ -318,7 +319,11 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
                     T ov[LC];
 #pragma unroll
                     for (int k = 0; k < LC; ++k) ov[k] = (T)v[k];
+#ifdef PN_CONV3_NT_STORE
+                    __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(ov), reinterpret_cast<PN_GLOBAL u32x4 *>(op));
+#else
                     *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
+#endif
                 } else {
                     for (int k = 0; k < LC; ++k)
                         if (cw + k < cout) op[k] = (T)v[k];

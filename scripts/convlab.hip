@@ -264,7 +264,12 @@ int main(int argc, char **argv) {
             auto pct = [](std::vector<double> &v, double p) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(p * v.size()))]; };
             printf(" block starts us: p50 %.1f p90 %.1f max %.1f | ends: p10 %.1f p50 %.1f p90 %.1f max %.1f  (%zu blocks)\n", pct(starts, .5), pct(starts, .9), starts.empty() ? 0 : starts.back(),
                    pct(ends, .1), pct(ends, .5), pct(ends, .9), ends.empty() ? 0 : ends.back(), starts.size());
-            for (int y = 0; y < nblocks / std::max(1, (int)(nblocks / std::max(1, 1))); ++y) break;
+            // in-kernel shader clock (MI355X_MICROARCH.md, DVFS give-back item 6): d(s_memtime) / d(s_memrealtime) x 100 MHz, median over blocks
+            std::vector<double> clk;
+            for (int b = 0; b < nblocks; ++b) if (st[b * 16 + 15] > st[b * 16 + 14] && st[b * 16 + 12] > st[b * 16])
+                clk.push_back((double)(st[b * 16 + 12] - st[b * 16]) / (double)(st[b * 16 + 15] - st[b * 16 + 14]) * 0.1);
+            std::sort(clk.begin(), clk.end());
+            printf(" in-kernel clock GHz: p10 %.3f p50 %.3f p90 %.3f (after %d back-to-back launches)\n", pct(clk, .1), pct(clk, .5), pct(clk, .9), iters);
         }
         for (int b = 0; b < std::min(nblocks, 4); ++b) { printf(" block %d:", b); for (int i = 0; i < 16; ++i) printf(" %lld", st[b*16+i] ? (long long)(st[b * 16 + i] - t0) : -1); printf("\n"); }
     }
