@@ -60,11 +60,17 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
 #ifndef PN_CONV3_NA2
 #define PN_CONV3_NA2 6
 #endif
-    constexpr int NA = KS == 1 ? 2 : (NBUF == 2 ? PN_CONV3_NA2 : 3);   // NSTEP % NA == 0: the queue slot of a k-step must not depend on the chunk
+#ifndef PN_CONV3_NA14
+#define PN_CONV3_NA14 3
+#endif
+#ifndef PN_CONV3_DB14
+#define PN_CONV3_DB14 6
+#endif
+    constexpr int NA = KS == 1 ? 2 : (NBUF == 2 ? PN_CONV3_NA2 : (PT == 14 ? PN_CONV3_NA14 : 3));   // NSTEP % NA == 0: the queue slot of a k-step must not depend on the chunk
     static_assert(NSTEP % NA == 0, "weight queue depth must divide the k-steps of a chunk");
     constexpr int IMG = 8 * PS;                        // bytes of one halo image
     constexpr int NITEM = NSTEP * PT;
-    constexpr int DB = 3;
+    constexpr int DB = PT == 14 ? PN_CONV3_DB14 : 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const ConvProblem &P = probs[blockIdx.y];

@@ -211,7 +211,9 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
             const long tiles112 = (long)n->max_batch * ((ib0.H + rows - 1) / rows) * segs;   // strip tiles of one wave group
             cs.wp = (cs.wc == 2 && rows == 4 && rpg == 4 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;   // big maps: 8-row tiles, 256 threads
             cs.rpg = rpg;
-            if (cs.wp == 2 && ks == 3 && cs.cin_chunks == 1 && getenv("POPNET_CONV3_PT14")) { cs.wp = 1; cs.pt = 14; cs.rpg = 8; }   // 8 rows per WAVE: half the weight bytes
+            if (cs.wp == 2 && ks == 3 && cs.cin_chunks == 1 && getenv("POPNET_CONV3_PT14") && atoi(getenv("POPNET_CONV3_PT14")) == 1) { cs.wp = 1; cs.pt = 14; cs.rpg = 8; }   // 8 rows per WAVE: half the weight bytes
+            if (const char *e = getenv("POPNET_CONV3_PT14"))          // =2: 128-cout blocks of 224-pixel wave tiles on every 28-column 3x3 level as well
+                if (atoi(e) == 2 && ks == 3 && cs.wc == 4 && cs.wp == 1 && rpg == 4 && rows == 4 && ib0.H >= 8) { cs.pt = 14; cs.rpg = 8; }
             const int hr = rpg * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
             // single halo image (4 waves / SIMD) beats the double-buffered variant (3 waves / SIMD) on every level
             // of both networks (profiles/README.md, r01 v8); POPNET_CONV3_NBUF2=1 selects the latter for experiments

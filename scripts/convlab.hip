@@ -175,7 +175,8 @@ int main(int argc, char **argv) {
         ConvProblem P; memset(&P, 0, sizeof P);
         int segs = (W + 29) / 30, Wt = (W + segs - 1) / segs;
         if (W % 28 == 0) Wt = 28;
-        int R = std::min(H, (112 * WP) / Wt);
+        const int lab_pt = getenv("PT") ? atoi(getenv("PT")) : 7;              // PT=14: 224-pixel wave tiles (8 rows x 28)
+        int R = std::min(H, (112 * WP * (lab_pt / 7)) / Wt);
         P.in = din2; P.in_zero_off = (unsigned)(hin.size() * 2);
         P.wpack = dpk; P.bias = dbias; P.res = use_res ? dres : nullptr; P.out = dout; P.B = B; P.H = H; P.W = W; P.Ho = H; P.Wo = W;
         P.cin_chunks = chunks; P.in_cs = cin_pad; P.cout = cout; P.out_cs = out_cs; P.res_cs = cout; P.act = act; P.R = R; P.Wt = Wt;
@@ -210,13 +211,18 @@ int main(int argc, char **argv) {
         const int gridx = maxb, gridy = (int)probs.size();
         lab_gridx = gridx; lab_gridy = gridy;
         const int nbuf = getenv("NBUF") ? atoi(getenv("NBUF")) : 1;
-        size_t lds = (size_t)8 * (4 * WP + ks - 1) * 32 * 16 * nbuf + 1024;
+        size_t lds = (size_t)8 * (4 * (lab_pt / 7) * WP + ks - 1) * 32 * 16 * nbuf + 1024;
         printf("v3 kernel: cfg %d (WC %d WP %d) NBUF %d R %d Wt %d blocks %d lds %zu\n", cfg, WC, WP, nbuf, R, Wt, nblocks, lds);
         auto launch = [&]() {
             dim3 grid(gridx, gridy);
 #define LAB3(KS_, WC_, WP_, NB_) if (ks == KS_ && WC == WC_ && WP == WP_ && nbuf == NB_) { auto kern = conv3_kernel<KS_, WC_, WP_, NB_, 7, 4>; \
                 if (lds > 48 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL(kern, grid, dim3(WC_ * WP_ * 64), lds, 0, dP); return; }
+            if (lab_pt == 14 && ks == 3 && WP == 1 && nbuf == 1 && (WC == 4 || WC == 2)) {
+                if (WC == 4) { auto kern = conv3_kernel<3, 4, 1, 1, 14, 8>; CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, dP); }
+                else { auto kern = conv3_kernel<3, 2, 1, 1, 14, 8>; hipLaunchKernelGGL(kern, grid, dim3(128), lds, 0, dP); }
+                return; }
             LAB3(3, 4, 1, 1) LAB3(3, 2, 2, 1) LAB3(3, 2, 1, 1) LAB3(3, 4, 1, 2) LAB3(3, 2, 2, 2) LAB3(3, 2, 1, 2) LAB3(3, 4, 2, 1)
             fprintf(stderr, "no v3 instantiation\n"); exit(1);
         };
