@@ -28,6 +28,9 @@
 #define PN_CONV3_OCC 4
 #endif
 // -DPN_CONV3_NT_STORE: output tiles leave with the nt hint (experiment v21: faster alone, slower in the network, where the next layer re-reads them)
+#ifndef PN_CONV3_FAST_EPILOGUE
+#define PN_CONV3_FAST_EPILOGUE 2  // wave-uniform fast epilogue: 0 never, 1 every instantiation, 2 the 128-cout blocks only (profiles/README.md v23)
+#endif
 #ifndef PN_CONV3_PIECEMAJOR
 #define PN_CONV3_HALFMAJOR 1      // LDS halo layout, see the header comment; -DPN_CONV3_PIECEMAJOR selects the first layout (experiments)
 #endif
@@ -105,15 +108,22 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
 
     // ---- weight stream: scalar base per cout tile + lane offset; first NA-1 k-steps in flight ----
     const int ctile0 = (cb * WC + wc) * CT;
-    gcptr wbase[CT];
+    // buffer loads: one resource for the whole pack, scalar fragment offset, 32-bit lane offset -- no vector ALU
+    // work and no 64-bit address registers per k-step (the flat form cost 2 v_lshl_add_u64 + 6 VGPRs)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(P.wpack), 0, 0x7fffffff, 0x00020000);
+    unsigned wbase[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) wbase[ct] = (gcptr)P.wpack + (size_t)(ctile0 + ct) * P.ksteps * FRAGB;
+    for (int ct = 0; ct < CT; ++ct) wbase[ct] = (unsigned)__builtin_amdgcn_readfirstlane((ctile0 + ct) * P.ksteps * FRAGB);
     const unsigned wlane = (unsigned)lane * 16u;
+    auto load_w = [&](unsigned soff) -> Frag {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, soff, 0);
+        return __builtin_bit_cast(Frag, r);
+    };
     Frag aq[NA][CT];
 #pragma unroll
     for (int d = 0; d < NA - 1; ++d)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = load_a_frag2<PN_PREC_BF16>(wbase[ct] + d * FRAGB, wlane);
+        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = load_w(wbase[ct] + d * FRAGB);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) wbase[ct] += (NA - 1) * FRAGB;
 
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {        // wpack ends with NA-1 spare fragments
 #ifndef PN_CONV3_FAKE_NOA                                // timing experiments only (wrong results)
-                    aq[(s + NA - 1) % NA][ct] = load_a_frag2<PN_PREC_BF16>(wbase[ct], wlane);
+                    aq[(s + NA - 1) % NA][ct] = load_w(wbase[ct]);
 #endif
 #ifndef PN_CONV3_FAKE_SAMEA                              // timing experiment: every weight load hits the same (L1-resident) KB
                     wbase[ct] += FRAGB;
@@ -343,6 +353,73 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
             }
         }
     };
+#if defined(PN_CONV3_HALFMAJOR)
+    // Fast path, chosen per WAVE (every condition is wave-uniform, so no exec-mask branching): all 32 couts of the wave
+    // exist, NHWC output only, a compile-time activation.  The pixel of a slot is recovered from its LDS read address
+    // (baddr = q*16 + (ry*32 + rx)*64) instead of being divided out again; same arithmetic on the values as `finish`,
+    // so the results are bit-identical (tests: conv3 == generic kernel).
+    const int wave_c0 = (cb * WC + wc) * (CT * 16);
+    const bool fast = (PN_CONV3_FAST_EPILOGUE == 1 || (PN_CONV3_FAST_EPILOGUE == 2 && WC == 4)) &&
+                      wave_c0 + CT * 16 <= cout && P.out && !nchw && (act == PN_ACT_RELU || act == PN_ACT_LEAKY || act == PN_ACT_NONE);
+    auto finish_fast = [&](auto actc, auto resc) {
+        constexpr int ACT = decltype(actc)::value;
+        constexpr bool RES = decltype(resc)::value;
+        PN_GLOBAL T *ob = (PN_GLOBAL T *)P.out + P.out_coff + wave_c0;
+        const PN_GLOBAL T *rb = (const PN_GLOBAL T *)P.res + P.res_coff + wave_c0;
+        const unsigned lane_c = (unsigned)(LC * q);
+        int ba[PT];                                       // opaque copies: keep the pixel arithmetic HERE (hoisted above the K loop it only adds spills)
+#pragma clang loop unroll(full)
+        for (int pt = 0; pt < PT; ++pt) { ba[pt] = baddr[pt]; asm volatile("" : "+v"(ba[pt])); }
+        u32x4 rq[PT];
+        if (RES) {
+#pragma clang loop unroll(full)
+            for (int pt = 0; pt < PT; ++pt) {
+                const unsigned t = (unsigned)ba[pt] >> 6;
+                const unsigned opix = (unsigned)pix0 + (t >> 5) * (unsigned)Wo + (t & 31u);
+                rq[pt] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(rb + (opix * (unsigned)res_cs + lane_c));
+            }
+        }
+#pragma clang loop unroll(full)
+        for (int pt = 0; pt < PT; ++pt) {
+            const int slot = (wp * PT + pt) * 16 + c;
+            const unsigned t = (unsigned)ba[pt] >> 6;
+            const unsigned opix = (unsigned)pix0 + (t >> 5) * (unsigned)Wo + (t & 31u);
+            float v[LC];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * ct + i] = acc[ct][pt][i] + bias[4 * ct + i];
+            if (RES) {
+                T rv[LC];
+                *reinterpret_cast<u32x4 *>(rv) = rq[pt];
+#pragma unroll
+                for (int k = 0; k < LC; ++k) v[k] += (float)rv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < LC; ++k) {
+                if (ACT == PN_ACT_RELU) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                else if (ACT == PN_ACT_LEAKY) v[k] = v[k] > 0.f ? v[k] : v[k] * 0.1f;
+            }
+            T ov[LC];
+#pragma unroll
+            for (int k = 0; k < LC; ++k) ov[k] = (T)v[k];
+            if (slot < npix) *reinterpret_cast<PN_GLOBAL u32x4 *>(ob + (opix * (unsigned)out_cs + lane_c)) = *reinterpret_cast<u32x4 *>(ov);
+        }
+    };
+    if (fast) {
+        if (P.res) {
+            if (act == PN_ACT_RELU) finish_fast(std::integral_constant<int, PN_ACT_RELU>{}, std::true_type{});
+            else if (act == PN_ACT_LEAKY) finish_fast(std::integral_constant<int, PN_ACT_LEAKY>{}, std::true_type{});
+            else finish_fast(std::integral_constant<int, PN_ACT_NONE>{}, std::true_type{});
+        } else {
+            if (act == PN_ACT_RELU) finish_fast(std::integral_constant<int, PN_ACT_RELU>{}, std::false_type{});
+            else if (act == PN_ACT_LEAKY) finish_fast(std::integral_constant<int, PN_ACT_LEAKY>{}, std::false_type{});
+            else finish_fast(std::integral_constant<int, PN_ACT_NONE>{}, std::false_type{});
+        }
+        PN_STAMP_AT(12);
+        return;
+    }
+#endif
     if (act == PN_ACT_RELU) finish(std::integral_constant<int, PN_ACT_RELU>{});
     else if (act == PN_ACT_LEAKY) finish(std::integral_constant<int, PN_ACT_LEAKY>{});
     else if (act == PN_ACT_NONE) finish(std::integral_constant<int, PN_ACT_NONE>{});
