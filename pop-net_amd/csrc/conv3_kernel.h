@@ -73,7 +73,10 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     static_assert(NSTEP % NA == 0, "weight queue depth must divide the k-steps of a chunk");
     constexpr int IMG = 8 * PS;                        // bytes of one halo image
     constexpr int NITEM = NSTEP * PT;
-    constexpr int DB = PT == 14 ? PN_CONV3_DB14 : 3;
+#ifndef PN_CONV3_DB
+#define PN_CONV3_DB 3
+#endif
+    constexpr int DB = PT == 14 ? PN_CONV3_DB14 : PN_CONV3_DB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const ConvProblem &P = probs[blockIdx.y];

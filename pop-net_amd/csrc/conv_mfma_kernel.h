@@ -154,6 +154,19 @@ template <int PREC, int KS, int STRIDE, int PITCH, int CFG> struct StageCfg {
 template <int PREC> __device__ __forceinline__ typename Elem<PREC>::Frag load_a_frag2(gcptr base, unsigned voff) {
     return load_a_frag<PREC>(base + voff);
 }
+// Same stream through a buffer resource: fragment offset in an SGPR, 32-bit lane offset -- hipcc otherwise widens
+// the lane offset to 64 bits and rebuilds a VGPR address pair per load (2 VALU + 6 VGPRs per k-step, measured:
+// profiles/README.md v23).
+template <int PREC> __device__ __forceinline__ typename Elem<PREC>::Frag load_a_frag_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ Elem<PN_PREC_BF16>::Frag load_a_frag_buf<PN_PREC_BF16>(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(Elem<PN_PREC_BF16>::Frag, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+template <> __device__ __forceinline__ Elem<PN_PREC_F32>::Frag load_a_frag_buf<PN_PREC_F32>(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    Elem<PN_PREC_F32>::Frag f;
+    f.lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    f.hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + 1024u, 0));
+    return f;
+}
 
 template <int PREC, int KS, int STRIDE, int PITCH, int CFG>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__restrict__ probs) {
@@ -242,10 +255,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
 
     // weight stream: scalar base per cout tile + lane offset
     const int ctile0 = (cb * WC + wc) * CT;
-    gcptr wbase[CT];
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(P.wpack), 0, 0x7fffffff, 0x00020000);
+    unsigned wbase[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) wbase[ct] = (gcptr)P.wpack + (size_t)(ctile0 + ct) * P.ksteps * FRAGB;
+    for (int ct = 0; ct < CT; ++ct) wbase[ct] = (unsigned)__builtin_amdgcn_readfirstlane((ctile0 + ct) * P.ksteps * FRAGB);
     const unsigned wlane = (unsigned)lane * 16u;
+    // bf16: buffer loads (fewer VGPRs); fp32 parity mode: the flat form measured 2 % faster (two loads per fragment)
+#define PN_LOAD_W(off) load_w(off)
+    auto load_w = [&](unsigned off) {
+        if constexpr (PREC == PN_PREC_F32) return load_a_frag2<PREC>((gcptr)P.wpack + off, wlane);
+        else return load_a_frag_buf<PREC>(wrsrc, wlane, off);
+    };
 
     // halo staging: thread -> 16-B piece `ch` of halo pixels p0, p0+PPI, ...; coordinates advance
     // incrementally (no division per piece), global offsets are 32-bit from a scalar image base.
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
 #pragma unroll
     for (int d = 0; d < NA - 1; ++d)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = load_a_frag2<PREC>(wbase[ct] + d * FRAGB, wlane);
+        for (int ct = 0; ct < CT; ++ct) aq[d][ct] = PN_LOAD_W(wbase[ct] + d * FRAGB);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) wbase[ct] += (NA - 1) * FRAGB;
     if (MAXST > 0) { stage_load(0); stage_store(buf0); }
@@ -348,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
                 if (pt == 0) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {    // wpack ends with NA-1 spare fragments
-                        aq[(s + NA - 1) % NA][ct] = load_a_frag2<PREC>(wbase[ct], wlane);
+                        aq[(s + NA - 1) % NA][ct] = PN_LOAD_W(wbase[ct]);
                         wbase[ct] += FRAGB;
                     }
                 }
