@@ -170,9 +170,9 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
 #ifndef PN_CONV3_FAKE_NODMA                               // timing experiment (wrong results): no halo fetch at all
         pn_glds16(img + chunk * 128 + (inb ? off : zrel),
 #ifdef PN_CONV3_HALFMAJOR
-                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + dst_hm : NBUF * IMG));
+                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + dst_hm : (NBUF >= 3 ? nchunks : NBUF) * IMG));
 #else
-                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + pc * PS + i * (2 * PITCH * 16) + dst_hm : NBUF * IMG));
+                  (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + pc * PS + i * (2 * PITCH * 16) + dst_hm : (NBUF >= 3 ? nchunks : NBUF) * IMG));
 #endif
 #endif
     };
@@ -181,6 +181,8 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
         for (int j = 0; j < NGW; ++j) stage_one(chunk, j, bufoff, true);
     };
     stage(0, 0);
+    if (NBUF >= 3)                                       // all-resident mode (1x1 convs, Cin <= 64 * NBUF): every chunk's image up front, no hand-over
+        for (int ch = 1; ch < nchunks; ++ch) stage(ch, ch * IMG);
 
     // ---- per-lane LDS read address of each pixel tile (tap / half are immediates) ----
     int baddr[PT];
@@ -210,12 +212,12 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     __syncthreads();
     PN_STAMP_AT(2);
 
-    static_assert(NBUF == 1 || NGW <= NSTEP, "the next chunk's DMA is spread one instruction per k-step");
+    static_assert(NBUF != 2 || NGW <= NSTEP, "the next chunk's DMA is spread one instruction per k-step");
     // a wave whose 32 couts lie beyond the layer's cout (a 64-cout conv sharing the launch of a 128-cout
     // sibling, net.hip::harmonize_level) only takes part in the halo DMA and the barriers
     const bool active = (cb * WC + wc) * (CT * 16) < P.cout;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int cur = NBUF == 2 ? (chunk & 1) * IMG : 0;
+        const int cur = NBUF == 2 ? (chunk & 1) * IMG : (NBUF >= 3 ? chunk * IMG : 0);
         const int nxt = NBUF == 2 ? IMG - cur : 0;
         const bool more = chunk + 1 < nchunks;
         const char *sm = smem + cur;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
 #undef PN3_OFF
         }
         PN_STAMP_AT(3 + 2 * (chunk & 3));
-        if (more) {
+        if (more && NBUF < 3) {
             if (NBUF == 2) {
                 // every DMA is older than the 2*(NA-1) weight loads in flight: wait for exactly those
                 if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA - 1)) : "memory");

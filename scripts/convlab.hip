@@ -211,7 +211,7 @@ int main(int argc, char **argv) {
         const int gridx = maxb, gridy = (int)probs.size();
         lab_gridx = gridx; lab_gridy = gridy;
         const int nbuf = getenv("NBUF") ? atoi(getenv("NBUF")) : 1;
-        size_t lds = (size_t)8 * (4 * (lab_pt / 7) * WP + ks - 1) * 32 * 16 * nbuf + 1024;
+        size_t lds = (size_t)8 * (4 * (lab_pt / 7) * WP + ks - 1) * 32 * 16 * (nbuf >= 3 ? std::min(nbuf, chunks) : nbuf) + 1024;   // nbuf >= 3: all Cin chunks resident
         printf("v3 kernel: cfg %d (WC %d WP %d) NBUF %d R %d Wt %d blocks %d lds %zu\n", cfg, WC, WP, nbuf, R, Wt, nblocks, lds);
         auto launch = [&]() {
             dim3 grid(gridx, gridy);
@@ -223,6 +223,7 @@ int main(int argc, char **argv) {
                     hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, dP); }
                 else { auto kern = conv3_kernel<3, 2, 1, 1, 14, 8>; hipLaunchKernelGGL(kern, grid, dim3(128), lds, 0, dP); }
                 return; }
+            LAB3(1, 4, 1, 1) LAB3(1, 4, 1, 4)
             LAB3(3, 4, 1, 1) LAB3(3, 2, 2, 1) LAB3(3, 2, 1, 1) LAB3(3, 4, 1, 2) LAB3(3, 2, 2, 2) LAB3(3, 2, 1, 2) LAB3(3, 4, 2, 1)
             fprintf(stderr, "no v3 instantiation\n"); exit(1);
         };
