@@ -169,6 +169,33 @@ def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, mo
         assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y)
 
 
+@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1"])
+def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, monkeypatch):
+    """The experiment switches of profiles/README.md (224-pixel wave tiles, double-buffered halo images, 8-row tiles on
+    14-column maps) select other conv3_kernel instantiations of the same arithmetic: same maps, bit for bit, as the
+    default build of the net (rtpose at 224x224 with a ragged batch of 5; YoloPoseNet for its 14x14 layers)."""
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    x = torch.from_numpy(np.random.default_rng(16).normal(0, 1, (5, 1, 224, 224)).astype(np.float32)).to(gpu)
+
+    def yolo():
+        m = YoloPoseNet(15, input_dim=1).eval()
+        m.load_state_dict(state_dict_from_keys(golden.keys["yolo_posenet"], seed=1))
+        m.precision = "bf16"
+        return m
+
+    ref = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
+    ref_y = yolo()(x).clone()
+    k, v = switch.split("=")
+    monkeypatch.setenv(k, v)                               # read when the net is compiled
+    got = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
+    got_y = yolo()(x).clone()
+    monkeypatch.delenv(k)
+    torch.cuda.synchronize()
+    for a, b, name in zip(got, ref, ("paf", "heat", "z")):
+        assert torch.isfinite(a).all() and torch.equal(a, b), (switch, name)
+    assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y), switch
+
+
 def test_bf16_batch_invariance_and_ragged_batches(gpu, golden):
     """Same as the fp32 invariance test, for the bf16 path (grouped launches, merged narrow convs, strip tiles)."""
     m = _rtpose(golden, "bf16")
