@@ -18,13 +18,14 @@
 template <typename TIN>
 __global__ void preprocess_kernel(const TIN *__restrict__ depth, float *__restrict__ out, int B, int H, int W, int S,
                                   double scale_x, double scale_y, float dmax, float mean, float stdv) {
-    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t total = (size_t)B * S * S;
-    if (gid >= total) return;
-    int dx = (int)(gid % S);
-    size_t t = gid / S;
-    int dy = (int)(t % S);
-    int b = (int)(t / S);
+    // blockIdx.y = frame, blockIdx.x * 256 + tid = pixel of the S x S output: 32-bit index arithmetic only (the first
+    // version divided a 64-bit linear index three times per pixel -- most of its 17.7 us per 32 frames)
+    const unsigned pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (unsigned)(S * S)) return;
+    const int b = blockIdx.y;
+    const int dy = (int)(pix / (unsigned)S);
+    const int dx = (int)(pix - (unsigned)dy * (unsigned)S);
+    const size_t gid = (size_t)b * S * S + pix;
 
     float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
     int sx = (int)floorf(fx);
@@ -99,8 +100,8 @@ int pn_preprocess(pn_ctx *ctx, const void *depth_dev, int depth_dtype, int B, in
         return pn_set_error(ctx, PN_ERR_INVALID, "pn_preprocess: bad arguments");
     const double inv_x = (double)S / (double)W, inv_y = (double)S / (double)H;
     const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;   // as cv::resize computes them
-    size_t total = (size_t)B * S * S;
-    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (B > 65535 || (size_t)S * S > 0x7fffffffu) return pn_set_error(ctx, PN_ERR_INVALID, "pn_preprocess: batch or output size out of range");
+    dim3 grid((unsigned)(((size_t)S * S + 255) / 256), (unsigned)B), block(256);
     hipStream_t s = (hipStream_t)hip_stream;
     if (depth_dtype == PN_DEPTH_F16)
         hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, block, 0, s, (const _Float16 *)depth_dev, out_dev, B, H, W, S,
