@@ -1,17 +1,25 @@
 #!/usr/bin/env python
 """Headline benchmark: end-to-end depth-frames/s (480x640 f16 frames -> 3D joints) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One step = one batch of 32 synthetic 480(w)x640(h) depth frames, already resident in HBM, through
-the whole hot path on one GPU: pn_preprocess -> rtpose_light3d forward (bf16 MFMA) -> pose parsing
--> records copied to pinned host memory.  This is BASELINE.json configs[1].  Weights are seeded
-random with the heat head calibrated to a realistic peak density (pipeline.calibrate_heads); data is
-synthetic (no dataset / checkpoint ships with the reference).
+N > 1 from a bare shell: bench.py starts N fresh ranks itself (torch.distributed.run, one process per GPU, RCCL over
+xGMI) BEFORE anything touches the GPU and relays rank 0's JSON line; started under torch.distributed.run it is a rank.
 
-Multi-GPU: weak scaling, every rank runs its own 32-frame batches (frames are independent, no
-collective on the data path) and ONE all-gather of the pose records over RCCL/xGMI closes the timed
-region.  Prints exactly one JSON line on rank 0.
+One step = one batch of 32 synthetic 480(w)x640(h) depth frames through the whole hot path on one GPU:
+pn_preprocess -> rtpose_light3d forward (bf16 MFMA) -> pose parsing -> compact records copied to pinned host memory
+(BASELINE.json configs[1]).  Every step takes a DIFFERENT batch: 18 distinct batches (354 MB, more than the 256 MB
+Infinity Cache) rotate through the three in-flight slots.  The K-step timed region runs `--reps` (5) times per input
+mode and the MEDIAN is reported, with min / max:
+  * `value`               inputs already resident in HBM when the region starts (the bench contract);
+  * `h2d_inclusive.value` every batch handed over from pinned host memory inside the region (19.7 MB per step over
+                          PCIe, on the slot's stream) -- SURVEY 8(d)'s "first H2D enqueue to last record on host".
+Weights are seeded random with the heat head calibrated to a realistic peak density (pipeline.calibrate_heads); data
+is synthetic (no dataset / checkpoint ships with the reference).
+
+Multi-GPU: weak scaling, every rank runs its own 32-frame batches (frames are independent, no collective on the data
+path) and ONE all-gather of the pose records over RCCL/xGMI closes every timed region.  Prints exactly one JSON line
+on rank 0.
 """
 import argparse
 import ctypes as C
@@ -27,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = int(os.environ.get("POPNET_BENCH_BATCH", "32"))     # 32 = BASELINE configs[1]; the override is for experiments only
-PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}      # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def cpu_baseline(engine, depth_host, frames_sample=32, reps=6):
@@ -65,27 +73,77 @@ def cpu_baseline(engine, depth_host, frames_sample=32, reps=6):
                       "numpy parse %.2fs (1 thread)" % (len(d), t_pre, t_fwd, threads, cores, t_parse)}
 
 
+def mpaug_parse_leg(engine, reps=20):
+    """BASELINE configs[3] (multi-person stream, >= 4 persons per frame): the pose-assembly kernels on planted maps with
+    4 / 6 / 8 overlapping persons per frame, 32 frames per launch; HIP-event time of pn_parse_paf."""
+    from popnet_amd import synth
+    out = {}
+    dev = engine.device
+    for persons in (2, 4, 6, 8):
+        heat, paf, z = synth.planted_batch(4242 + persons, [persons] * engine.max_batch, noise=0.01)
+        engine.heat.copy_(torch.from_numpy(heat).to(dev))
+        engine.paf.copy_(torch.from_numpy(paf).to(dev))
+        engine.z.copy_(torch.from_numpy(z).to(dev))
+        for _ in range(3):
+            engine.parse(engine.max_batch)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            engine.parse(engine.max_batch)
+        b.record()
+        torch.cuda.synchronize()
+        from popnet_amd.pipeline import records_to_numpy
+        recs = records_to_numpy(engine.frames)
+        out["%d_persons" % persons] = {"parse_us_per_step": round(a.elapsed_time(b) * 1e3 / reps, 2),
+                                       "mean_persons_found": round(float(recs["n_persons"].mean()), 2),
+                                       "mean_peaks": round(float(recs["n_peaks"].mean()), 1),
+                                       "overflow_frames": int((recs["status"] != 0).sum())}
+    return out
+
+
+def launcher_dry_run(args):
+    """CPU check of the self-launch path: every rank joins a gloo group, rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launcher_dry_run": True, "n_gpus": world, "rank_sum": int(t.item()), "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--net", default="rtpose", choices=["rtpose", "yolo"],
                     help="rtpose = rtpose_light3d + PAF parsing (the headline workload); yolo = YoloPoseNet + box decode (SURVEY 8a rows 7, 12)")
-    ap.add_argument("--h2d", action="store_true", help="hand every batch over from pinned host memory (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive passes (inputs handed over from pinned host memory)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fidelity / multi-person legs (profiling runs)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight per GPU (engines on separate HIP streams)")
+    ap.add_argument("--pool", type=int, default=6, help="distinct input batches per slot (pipeline x pool x 19.7 MB should exceed the 256 MB Infinity Cache)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region per input mode; the median is reported")
+    ap.add_argument("--launcher-dry-run", action="store_true", help="CPU check of the --gpus N self-launch (gloo, no GPU work)")
     args = ap.parse_args()
+
+    from popnet_amd import launch                                   # touches no GPU
+    if args.gpus > 1 and not launch.under_torchrun():
+        # started from a bare shell: become the parent of N fresh ranks (nothing below this line has run, no HIP call yet)
+        sys.exit(launch.relaunch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.launcher_dry_run:
+        return launcher_dry_run(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -96,99 +154,111 @@ def main():
 
     import popnet_amd  # noqa: F401
     from popnet_amd import _lib, synth
-    from popnet_amd.pipeline import PoseEngine, YoloEngine
+    from popnet_amd.pipeline import PoseEngine, StreamingEngine, YoloEngine
     Engine = PoseEngine if args.net == "rtpose" else YoloEngine
     REC = _lib.POSE_FRAME_DTYPE if args.net == "rtpose" else _lib.YOLO_FRAME_DTYPE
+    WIRE = _lib.POSE_WIRE_DTYPE if args.net == "rtpose" else REC
 
-    # popnet_amd.pipeline.StreamingEngine: PIPE batches in flight (per slot: engine = activations + parse workspace,
-    # static input, record buffers, HIP stream, ONE hipGraph of the whole step).  Batch k runs on slot k % PIPE, so the
-    # latency-bound tail of one batch (head convs, pose parsing, the record D2H copy) overlaps with the convolutions of
-    # the next.  Every batch still runs the whole path; only its latency, not the work, is hidden.
-    from popnet_amd.pipeline import StreamingEngine
-    PIPE = max(1, args.pipeline)
-    se = StreamingEngine(Engine, depth=PIPE, graph=not args.no_graph, precision=args.precision, device=dev, max_batch=BATCH)
+    # popnet_amd.pipeline.StreamingEngine: PIPE batches in flight (per slot: engine = activations + private parse scratch,
+    # POOL static input buffers, record buffers, a HIP stream, ONE hipGraph of the whole step per input buffer).  Batch k
+    # runs on slot k % PIPE, so the latency-bound tail of one batch (head convs, pose parsing, the record D2H copy)
+    # overlaps with the convolutions of the next.  Every batch still runs the whole path; only its latency is hidden.
+    PIPE, POOL = max(1, args.pipeline), max(1, args.pool)
+    NIN = PIPE * POOL
+    se = StreamingEngine(Engine, depth=PIPE, pool=POOL, wire=True, graph=not args.no_graph, precision=args.precision, device=dev, max_batch=BATCH)
     engines, streams = se.engines, se.streams
     engine = engines[0]
-    depth_host = synth.synth_depth(BATCH, 640, 480, seed=1234 + rank)
-    for sl in range(PIPE):
-        se.input(sl).copy_(torch.from_numpy(depth_host))          # inputs resident in HBM before the timed region
+    pinned = []                                                  # NIN distinct batches, pinned on the host ...
+    for i in range(NIN):
+        h = torch.from_numpy(synth.synth_depth(BATCH, 640, 480, seed=1234 + 1000 * rank + i)).pin_memory()
+        pinned.append(h)
+        se.input(i // POOL, i % POOL).copy_(h)                   # ... and resident in HBM (slot i // POOL, buffer i % POOL)
+    depth_host = pinned[0].numpy()
     torch.cuda.synchronize()
     K, W = args.steps, args.warmup
-    item = REC.itemsize
-    frames_dev = torch.empty((K, BATCH, item), device=dev, dtype=torch.uint8)
-    # what crosses xGMI in the closing all-gather: compact pn_pose_wire records (6.2 KB instead of 33 KB per frame) for
-    # the PAF path, the (already small) pn_yolo_frame records for the yolo path
-    witem = _lib.POSE_WIRE_DTYPE.itemsize if args.net == "rtpose" else item
-    wire_dev = torch.empty((K, BATCH, witem), device=dev, dtype=torch.uint8) if world > 1 else None
+    witem = WIRE.itemsize
+    keep = torch.empty((K, BATCH, witem), device=dev, dtype=torch.uint8)       # every step's host-bound records (checks, gather)
     gathered = torch.empty((world * K * BATCH, witem), device=dev, dtype=torch.uint8) if world > 1 else None
 
-    pinned = torch.from_numpy(depth_host).pin_memory() if args.h2d else None
+    def input_id(k):                                             # step k -> (slot, buffer): all NIN batches in turn
+        return k % PIPE, (k // PIPE) % POOL
 
-    def step(k):
-        if pinned is not None:                                         # PCIe-inclusive variant: 19.7 MB per batch on the slot's stream
-            sl = se._tickets % PIPE
+    def step(k, h2d):
+        sl, j = input_id(k)
+        if h2d:                                                  # PCIe-inclusive: 19.7 MB per batch on the slot's stream
             with torch.cuda.stream(se.stream(sl)):
-                se.input(sl).copy_(pinned, non_blocking=True)
-        t = se.submit()
+                se.input(sl, 0).copy_(pinned[sl * POOL + j], non_blocking=True)
+            j = 0
+        t = se.submit(j)
         with torch.cuda.stream(se.stream(t)):
-            frames_dev[k].copy_(se.records(t), non_blocking=True)          # keep every step's records (rank-0 statistics)
-            if world > 1:                                                  # ... and their wire form for the final gather
-                if args.net == "rtpose":
-                    engines[t % PIPE].pack(se.records(t), wire_dev[k])
-                else:
-                    wire_dev[k].copy_(se.records(t), non_blocking=True)
+            keep[k].copy_(se.wires[t % PIPE] if se.wire else se.records(t), non_blocking=True)
 
-    def join():
+    def region(h2d):
+        """K steps, barrier + device sync on both sides, max over ranks.  Returns seconds."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(K):
+            step(k, h2d)
         se.join()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, keep.view(K * BATCH, witem))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     se.capture()
     for i in range(max(W, 2 * PIPE)):
-        step(i % K)
-    join()
+        step(i % K, False)
+    se.join()
     if world > 1:
-        dist.all_gather_into_tensor(gathered, wire_dev.view(K * BATCH, witem))
+        dist.all_gather_into_tensor(gathered, keep.view(K * BATCH, witem))
     torch.cuda.synchronize()
 
-    # ---- timed region: K steps, barrier + device sync on both sides, max over ranks ----
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        step(k)
-    join()
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, wire_dev.view(K * BATCH, witem))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    frames_host = frames_dev.cpu()
+    REPS = max(1, args.reps)
+    runs = {"resident": [region(False) for _ in range(REPS)]}
+    keep_res = keep.cpu()
+    if not args.no_h2d:
+        region(True)                                             # one untimed pass: first touch of the pinned pool
+        runs["h2d"] = [region(True) for _ in range(REPS)]
+        keep_h2d = keep.cpu()
+        for sl in range(PIPE):                                   # buffer 0 of every slot was the hand-over target: restore its own batch
+            se.input(sl, 0).copy_(pinned[sl * POOL])
+        torch.cuda.synchronize()
+    med = {m: float(np.median(v)) for m, v in runs.items()}
+    elapsed = med["resident"]
 
-    # ---- roofline pass: the same K steps again, eager, every conv launch bracketed by HIP events on
-    # the launch stream (event records inside the throughput pass would perturb it) ----
+    # ---- roofline pass: K steps again, eager, every conv launch bracketed by HIP events on the launch stream (event
+    # records inside the throughput pass would perturb it) ----
     L = _lib.lib()
     torch.cuda.synchronize()
     L.pn_net_profile_begin(engine.net)                           # only slot 0's net records events: its launches alone
     t1 = time.perf_counter()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
     with torch.cuda.stream(streams[0]):
         for k in range(K):
-            nb = engine.preprocess(se.input(0))
+            nb = engine.preprocess(se.input(0, k % POOL))
             engine.forward(nb)
             ev[k][0].record()
             engine.parse(nb, se.records(0))                  # post-processing kernels of this step, bracketed on their stream
             ev[k][1].record()
-            se.host_records(0).copy_(se.records(0), non_blocking=True)
+            if se.wire:
+                engine.pack(se.records(0), se.wires[0])
             ev[k][2].record()
+            se.host_records(0).copy_(se.wires[0] if se.wire else se.records(0), non_blocking=True)
+            ev[k][3].record()
     torch.cuda.synchronize()
     elapsed_profiled = time.perf_counter() - t1
     post_ms = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
-    d2h_ms = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
+    pack_ms = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
+    d2h_ms = sum(ev[k][2].elapsed_time(ev[k][3]) for k in range(K)) / K
     conv_ms, other_ms, conv_flops = C.c_double(), C.c_double(), C.c_double()
     conv_n, other_n = C.c_int64(), C.c_int64()
     engine.ctx.check(L.pn_net_profile_end(engine.net, C.byref(conv_ms), C.byref(conv_n), C.byref(conv_flops),
@@ -203,16 +273,28 @@ def main():
                         "avg_launch_us": round(kms.value * 1e3 / max(kn.value, 1), 3),
                         "tflops": round(kfl.value / (kms.value * 1e-3) / 1e12, 2) if kms.value > 0 else 0.0,
                         "flops_per_launch": round(kfl.value / max(kn.value, 1), 1)})
+    frames_full = torch.stack([se.records(s) for s in range(PIPE)]).cpu()
 
     if rank == 0:
-        recs = frames_host.numpy().view(REC).reshape(K, BATCH)
-        raw = frames_host.numpy().reshape(K, -1)
-        same = bool(all(np.array_equal(raw[0], raw[k]) for k in range(1, K)))     # same input every step -> same records from every engine
+        def consistent(kept):                                    # the same input batch must give the same records, whatever step / slot / mode ran it
+            raw = kept.numpy().reshape(K, -1)
+            first = {}
+            for k in range(K):
+                i = input_id(k)
+                if i in first and not np.array_equal(raw[first[i]], raw[k]):
+                    return False
+                first.setdefault(i, k)
+            return True
+        same = consistent(keep_res)
+        if "h2d" in runs:
+            same = same and consistent(keep_h2d) and bool(torch.equal(keep_res, keep_h2d))
+        wire = keep_res.numpy().view(WIRE).reshape(K, BATCH)
+        recs = frames_full.numpy().view(REC).reshape(PIPE, BATCH)
         total_frames = world * K * BATCH
         achieved = conv_flops.value / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+        peak = PEAK_TFLOPS[args.precision]
         # network outputs read + records written per frame
-        post_bytes = BATCH * ((185024 if args.net == "rtpose" else 100 * 14 * 14 * 4) + item)
+        post_bytes = BATCH * ((185024 if args.net == "rtpose" else 100 * 14 * 14 * 4) + witem)
         dom = kernels[0] if kernels else {"kernel": "none", "us_per_step": 0.0, "avg_launch_us": 0.0, "tflops": 0.0, "flops_per_launch": 0.0, "launches_per_step": 0}
         traffic = None                                          # HBM bytes per launch of the dominant kernel (separate rocprofv3 --pmc passes)
         pmc = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
@@ -221,16 +303,24 @@ def main():
                 traffic = json.load(open(pmc)).get("by_kernel", {}).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+
+        def rate(sec):
+            return round(total_frames / sec, 2)
         out = {
-            "metric": "depth-frames/sec end-to-end (480x640)", "value": round(total_frames / elapsed, 2),
+            "metric": "depth-frames/sec end-to-end (480x640)", "value": rate(elapsed),
             "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 4), "launch_mode": ("eager" if args.no_graph else "hipGraph replay (one graph per step)") + ", %d batches in flight on separate HIP streams" % PIPE, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (", handed over from pinned host memory every step (PCIe-inclusive)" if args.h2d else ", resident in HBM"),
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "value_stat": {"what": "median of %d repetitions of the %d-step timed region" % (REPS, K), "min": rate(max(runs["resident"])), "max": rate(min(runs["resident"])),
+                           "runs": [rate(v) for v in runs["resident"]]},
+            "launch_mode": ("eager" if args.no_graph else "hipGraph replay (one graph per step)") + ", %d batches in flight on separate HIP streams" % PIPE, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic, %d distinct batches (%.0f MB) resident in HBM, a different batch every step" % (NIN, NIN * BATCH * 640 * 480 * 2 / 1e6),
             "config": {"workload": "BASELINE configs[1]: batch=32 synthetic 480x640 f16 depth frames per GPU per step, "
                                    "resize->224^2, " + ("rtpose_light3d forward + PAF pose parsing" if args.net == "rtpose" else
                                                         "YoloPoseNet forward + box decode / NMS / skeleton read-out (secondary network of the path)") + ", records D2H",
                        "frames_per_step_per_gpu": BATCH, "input": "480x640 f16", "network_input": "224x224",
                        "weights": "seeded random, " + ("heat head calibrated (pipeline.calibrate_heads)" if args.net == "rtpose" else "confidence filters calibrated (pipeline.calibrate_yolo_conf)"),
+                       "records": "pn_pose_wire (%d B per frame) to pinned host memory every step" % witem if se.wire else "pn_yolo_frame to pinned host memory every step",
                        "parallelism": "frames sharded x%d, one all-gather of records" % world},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"] + " (dominant convolution instantiation: %.0f of %.0f conv us/step)" % (dom["us_per_step"], conv_ms.value * 1e3 / K),
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
@@ -239,17 +329,23 @@ def main():
                          "conv_stack": {"achieved": round(achieved, 2), "frac": round(achieved / peak, 4), "launches_per_step": conv_n.value // max(K, 1),
                                         "ms_per_step": round(conv_ms.value / K, 4), "tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
                                         "stem_pool_ms_per_step": round(other_ms.value / K, 4), "by_kernel": kernels},
-                         "measured": "HIP events around every conv launch on the launch stream, the same %d steps re-run eagerly on one engine right after the timed region (%.4f ms/step with events)" % (K, elapsed_profiled / K * 1e3)},
+                         "measured": "HIP events around every conv launch on the launch stream, the same %d steps re-run eagerly on one engine right after the timed regions (%.4f ms/step with events)" % (K, elapsed_profiled / K * 1e3)},
             "postproc": {"bound": "hbm", "kernels": "pose parsing (NMS + refine, limb scoring + matching, assembly + read-out)" if args.net == "rtpose" else "box decode + NMS + skeleton read-out",
                          "algorithmic_bytes_per_step": post_bytes, "us_per_step": round(post_ms * 1e3, 2),
                          "achieved": round(post_bytes / (post_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(post_bytes / (post_ms * 1e-3) / 8e12, 5), "record_d2h_us_per_step": round(d2h_ms * 1e3, 2),
+                         "frac": round(post_bytes / (post_ms * 1e-3) / 8e12, 5), "pack_us_per_step": round(pack_ms * 1e3, 2), "record_d2h_us_per_step": round(d2h_ms * 1e3, 2),
                          "note": "latency-bound: 32 small frames per step; hidden behind the next batch by the StreamingEngine"},
             "frame_stats": {"mean_peaks": round(float(recs['n_peaks' if args.net == "rtpose" else 'n_candidates'].mean()), 2),
-                            "mean_persons": round(float(recs['n_persons' if args.net == "rtpose" else 'n_det'].mean()), 3),
-                            "overflow_frames": int((recs['status'] != 0).sum()),
-                            "records_identical_across_steps_and_engines": same},
+                            "mean_persons": round(float(wire['n_persons' if args.net == "rtpose" else 'n_det'].mean()), 3),
+                            "overflow_frames": int((wire['status'] != 0).sum()),
+                            "same_batch_same_records_across_steps_slots_and_input_modes": same},
         }
+        if "h2d" in runs:
+            out["h2d_inclusive"] = {"value": rate(med["h2d"]), "unit": "frames/s", "ms_per_step": round(med["h2d"] / K * 1e3, 4),
+                                    "min": rate(max(runs["h2d"])), "max": rate(min(runs["h2d"])), "runs": [rate(v) for v in runs["h2d"]],
+                                    "what": "same region, every batch copied from pinned host memory on its slot's stream inside the region (%.1f MB per step over PCIe): first H2D enqueue to last record on host, median of %d" % (BATCH * 640 * 480 * 2 / 1e6, REPS)}
+        if world == 1 and args.net == "rtpose" and not args.no_extras:
+            out["mpaug_parse"] = mpaug_parse_leg(engine)
         if world == 1 and not args.no_cpu_baseline and args.net == "rtpose":
             out["cpu_baseline"] = cpu_baseline(engine, depth_host)
         print(json.dumps(out))

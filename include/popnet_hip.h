@@ -106,6 +106,10 @@ int pn_net_read_activation(pn_net *net, const char *name, int B, float *host_out
 int pn_net_copy_activation(pn_net *net, const char *name, int B, float *dev_out, void *hip_stream);
 /* Algorithmic FLOPs (2*MAC, convolutions only) of one frame through the finalized net. */
 double pn_net_flops_per_frame(pn_net *net);
+/* Freezes the launch descriptors at the batch size / output pointers of the last forward: afterwards a forward with
+ * another batch size or other output buffers returns PN_ERR_STATE instead of rewriting descriptors that a captured
+ * hipGraph reads at replay time.  pn_net_lock(net, 0) lifts the freeze.                                               */
+int pn_net_lock(pn_net *net, int locked);
 /* Measurement hooks: between begin and end every kernel launch of pn_*_forward is bracketed by
  * HIP events recorded on the caller's stream.  end() waits for them and returns the summed
  * durations: conv_* = the MFMA convolution launches (with the algorithmic FLOPs they covered),
@@ -175,6 +179,11 @@ void pn_parse_cfg_default(pn_parse_cfg *cfg);
 int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev,
                  int B, int h, int w, const pn_parse_cfg *cfg, pn_pose_frame *frames_dev,
                  void *hip_stream);
+/* Sizes the context's parse scratch for batches of up to max_batch frames, once, so that pn_parse_paf never
+ * allocates on the launch path (a captured hipGraph keeps the scratch pointer: growing it later would free memory
+ * the graph still uses).  pn_parse_paf returns PN_ERR_STATE instead of growing the scratch while its stream is being
+ * captured, and after pn_parse_reserve has fixed the size.                                                          */
+int pn_parse_reserve(pn_ctx *ctx, int max_batch);
 
 /* retrieve_depth_heat_weighted(center, depthmap, heatmap, radius) (tpm/lib/utils/common.py:272-293)
  * for n centres (x, y int32 pairs) on one [h, w] f32 map pair; like the reference it first clamps

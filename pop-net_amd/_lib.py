@@ -88,6 +88,8 @@ _SIGNATURES = {
     "pn_net_read_activation": (_i, [_vp, C.c_char_p, _i, _vp, _sz, _vp]),
     "pn_net_copy_activation": (_i, [_vp, C.c_char_p, _i, _vp, _vp]),
     "pn_net_flops_per_frame": (_d, [_vp]),
+    "pn_net_lock": (_i, [_vp, _i]),
+    "pn_parse_reserve": (_i, [_vp, _i]),
     "pn_net_profile_begin": (_i, [_vp]),
     "pn_net_profile_end": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_int64), C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_int64)]),
     "pn_net_profile_kernel": (_i, [_vp, _i, C.c_char_p, _sz, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -91,6 +91,7 @@ struct pn_net {
     std::vector<void *> dev_allocs;
     float *nchw_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_B = -1;
+    bool locked = false;             // pn_net_lock: descriptors frozen (a captured hipGraph reads them at replay time)
     float *last_nchw[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<std::string, std::pair<int, std::pair<int, int>>> named;   // name -> (buf, (coff, C))
     double flops_per_frame = 0;
@@ -601,8 +602,11 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
     if (B < 1 || B > n->max_batch) return pn_set_error(ctx, PN_ERR_INVALID, "batch %d outside [1, %d]", B, n->max_batch);
     bool dirty = B != n->last_B;
     for (int i = 0; i < 4; ++i) dirty |= n->nchw_ptr[i] != n->last_nchw[i];
-    if (dirty)
+    if (dirty) {
+        if (n->locked)
+            return pn_set_error(ctx, PN_ERR_STATE, "net is locked at batch %d (pn_net_lock): a forward with another batch size or other output buffers would rewrite descriptors a captured graph still reads", n->last_B);
         if (int rc = refresh_problems(n, B, stream)) return rc;
+    }
     for (auto &st : n->steps) {
         int rc = PN_OK;
         pn_net::ProfRec *pr = nullptr;
@@ -694,6 +698,8 @@ int pn_net_finalize(pn_net *n, int precision, int max_batch, int in_h, int in_w)
     if (rc) return rc;
     for (auto &b : n->bufs) {
         size_t bytes = (size_t)max_batch * b.H * b.W * b.C * n->esize() + 256;   // + zero page (halo padding source of conv3_kernel)
+        if (bytes >= ((size_t)1 << 32))     // the kernels address a buffer with 32-bit byte offsets (zero page, epilogue stores)
+            return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "activation buffer %dx%dx%d x batch %d = %zu B exceeds the 4 GiB the kernels' 32-bit offsets address; lower max_batch", b.H, b.W, b.C, max_batch, bytes);
         if (int r = dev_alloc(n, &b.p, bytes, true)) return r;   // zero: pad channels must read as 0
     }
     for (auto &st : n->steps)
@@ -753,6 +759,13 @@ int pn_net_read_activation(pn_net *n, const char *name, int B, float *host_out, 
 }
 
 double pn_net_flops_per_frame(pn_net *n) { return n ? n->flops_per_frame : 0.0; }
+
+int pn_net_lock(pn_net *n, int locked) {
+    if (!n) return PN_ERR_INVALID;
+    if (locked && n->last_B < 0) return pn_set_error(n->ctx, PN_ERR_STATE, "pn_net_lock: run one forward first");
+    n->locked = locked != 0;
+    return PN_OK;
+}
 
 int pn_net_profile_begin(pn_net *n) {
     if (n) n->prof_by_kernel.clear();

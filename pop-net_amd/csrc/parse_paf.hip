@@ -513,6 +513,12 @@ extern "C" int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf
         return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_paf: built for downsample=8, 10 intermediate points");
     const size_t need = (size_t)B * sizeof(ParseWs);
     if (ctx->parse_ws_bytes < need) {
+        // never move the scratch under a graph: not while this stream is capturing, not once its size was fixed
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hip_stream && hipStreamIsCapturing((hipStream_t)hip_stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return pn_set_error(ctx, PN_ERR_STATE, "pn_parse_paf: batch %d needs a larger parse scratch while the stream is being captured (call pn_parse_reserve first)", B);
+        if (ctx->parse_ws_fixed)
+            return pn_set_error(ctx, PN_ERR_STATE, "pn_parse_paf: batch %d exceeds the batch size given to pn_parse_reserve", B);
         if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
         ctx->parse_ws = nullptr;
         ctx->parse_ws_bytes = 0;
@@ -532,6 +538,23 @@ extern "C" int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf
     hipLaunchKernelGGL(group_readout_kernel, dim3(B), dim3(64), 0, s, heat_dev, z_dev, h, w, J_ + 1, L_ + 1, *cfg,
                        (const ParseWs *)ws, frames_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+extern "C" int pn_parse_reserve(pn_ctx *ctx, int max_batch) {
+    if (!ctx) return PN_ERR_INVALID;
+    if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
+    if (max_batch < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_parse_reserve: max_batch must be >= 1");
+    const size_t need = (size_t)max_batch * sizeof(ParseWs);
+    if (ctx->parse_ws_bytes < need) {
+        if (ctx->parse_ws_fixed) return pn_set_error(ctx, PN_ERR_STATE, "pn_parse_reserve: the scratch size is already fixed at a smaller batch");
+        if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
+        ctx->parse_ws = nullptr;
+        ctx->parse_ws_bytes = 0;
+        PN_HIP_CHECK(ctx, hipMalloc(&ctx->parse_ws, need));
+        ctx->parse_ws_bytes = need;
+    }
+    ctx->parse_ws_fixed = true;
     return PN_OK;
 }
 

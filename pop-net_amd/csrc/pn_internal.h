@@ -12,6 +12,7 @@ struct pn_ctx {
     // scratch for the parse kernels (grown on demand, owned by the ctx)
     void *parse_ws = nullptr;
     size_t parse_ws_bytes = 0;
+    bool parse_ws_fixed = false;     // pn_parse_reserve: the scratch never moves again
 };
 
 int pn_set_error(pn_ctx *ctx, int code, const char *fmt, ...);

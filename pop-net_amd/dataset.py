@@ -123,6 +123,8 @@ def run_sweep_streaming(se, frames, batch_size=32, rank=0, world=1, drop_last=Fa
     if drop_last:
         n -= n % (batch_size * world)
     mine = shard_indices(n, rank, world)
+    if getattr(se, "wire", False):
+        raise _lib.PopnetError("run_sweep_streaming collects the full records: build the StreamingEngine with wire=False")
     item = se.recs[0].shape[1]
     bs = min(batch_size, se.max_batch)
     local = torch.empty((len(mine), item), dtype=torch.uint8, device=se.device)

@@ -40,9 +40,10 @@ class PoseEngine:
         self.model.precision = precision
         self.ctx = _lib.Context(self.device.index) if private_ctx else _lib.Context.for_device(self.device.index)
         self.L = _lib.lib()
-        self.net = self.model._compile(self.device, self.max_batch, self.S, self.S)
         self.cfg = make_parse_cfg(default_cfg(), input_size=self.S, w_org=w_org, h_org=h_org, intrinsics=intrinsics,
                                   depth_mean=DEPTH_MEAN, depth_std=DEPTH_STD)
+        # the parse scratch is sized once for max_batch: the launch path never reallocates (a captured graph keeps the pointer)
+        self.ctx.check(self.L.pn_parse_reserve(self.ctx.handle, self.max_batch), "pn_parse_reserve")
         h = self.S // 8
         d, f32 = self.device, torch.float32
         self.x = torch.empty((self.max_batch, 1, self.S, self.S), device=d, dtype=f32)
@@ -51,6 +52,19 @@ class PoseEngine:
         self.z = torch.empty((self.max_batch, 15, h, h), device=d, dtype=f32)
         self.frames = torch.empty((self.max_batch, _lib.POSE_FRAME_DTYPE.itemsize), device=d, dtype=torch.uint8)
         self.flops_per_frame = self.L.pn_net_flops_per_frame(self.net)
+
+    @property
+    def net(self):
+        """The model's CURRENT pn_net handle.  The module destroys its handle on invalidate() / load_state_dict() / a
+        forward at another size or precision, so the engine never keeps a raw copy: it re-reads (or re-compiles) here."""
+        cached = self.model._net
+        if cached is None or cached[2] < self.max_batch:
+            return self.model._compile(self.device, self.max_batch, self.S, self.S)
+        return cached[0]
+
+    def lock(self, locked=True):
+        """Freeze the net's launch descriptors (call after a warm-up forward, before capturing a hipGraph)."""
+        self.ctx.check(self.L.pn_net_lock(self.net, 1 if locked else 0), "pn_net_lock")
 
     # ---- stages (all asynchronous on the current stream) --------------------------------------
     def preprocess(self, depth):
@@ -128,7 +142,6 @@ class YoloEngine:
         self.model.precision = precision
         self.ctx = _lib.Context(self.device.index) if private_ctx else _lib.Context.for_device(self.device.index)
         self.L = _lib.lib()
-        self.net = self.model._compile(self.device, self.max_batch, self.S, self.S)
         self.cfg = make_parse_cfg(default_cfg(), input_size=self.S, w_org=w_org, h_org=h_org, intrinsics=intrinsics,
                                   depth_mean=DEPTH_MEAN, depth_std=DEPTH_STD)
         self.conf_threshold, self.nms_threshold = float(conf_threshold), float(nms_threshold)
@@ -142,6 +155,8 @@ class YoloEngine:
         self.flops_per_frame = self.L.pn_net_flops_per_frame(self.net)
 
     preprocess = PoseEngine.preprocess
+    net = PoseEngine.net
+    lock = PoseEngine.lock
 
     def forward(self, B):
         self.ctx.check(self.L.pn_yolo_forward(self.net, C.c_void_p(self.x.data_ptr()), B, C.c_void_p(self.out.data_ptr()),
@@ -208,67 +223,90 @@ def calibrate_yolo_conf(model, device=None, frac=0.012, calib_frames=8, seed=99)
 class StreamingEngine:
     """Throughput front end: `depth` batches in flight on one GPU.
 
-    Slot i owns a PoseEngine / YoloEngine (activations, parse workspace), a static input buffer, a device and a pinned
-    host record buffer, a HIP stream and -- once `capture()` has run -- ONE hipGraph of the whole step (pre-processing,
-    forward, parsing, record D2H copy).  `submit()` replays slot (ticket mod depth) on its stream and returns at once; the
-    latency-bound tail of a batch (head convolutions, pose assembly, the record copy) then overlaps with the convolutions
-    of the next batches (+35 % on one MI355X at depth 3).  Fill `input(slot)` (e.g. with a non_blocking
-    copy from pinned host memory issued on `stream(slot)`) before submitting; read `records(ticket)` / `host_records(ticket)`
-    after `wait(ticket)`.  A slot must be waited for before it is submitted again."""
+    Slot i owns a PoseEngine / YoloEngine (activations, a PRIVATE pn_ctx = its own parse scratch), `pool` static input
+    buffers, a device and a pinned host record buffer, a HIP stream and -- once `capture()` has run -- one hipGraph of
+    the whole step (pre-processing, forward, parsing, record D2H copy) PER INPUT BUFFER.  `submit(j)` replays slot
+    (ticket mod depth) on input buffer j of that slot and returns at once; the latency-bound tail of a batch (head
+    convolutions, pose assembly, the record copy) then overlaps with the convolutions of the next batches.  Fill
+    `input(slot, j)` (e.g. with a non_blocking copy from pinned host memory issued on `stream(slot)`) before
+    submitting; read `records(ticket)` / `host_records(ticket)` after `wait(ticket)`.  A slot must be waited for
+    before it is submitted again.
 
-    def __init__(self, engine_cls=None, depth=3, frame_hw=(640, 480), frame_dtype=torch.float16, graph=True, **engine_kw):
+    wire=True: what leaves the GPU per step is the compact pn_pose_wire form (6.2 KB instead of 33 KB per frame; PAF
+    path only): `host_records()` then holds pn_pose_wire records, `records()` still the full pn_pose_frame ones.
+
+    Every engine gets its own context and its net is locked after the warm-up (pn_net_lock): nothing a captured graph
+    points at (parse scratch, launch descriptors) can be reallocated or rewritten by a later eager call."""
+
+    def __init__(self, engine_cls=None, depth=3, frame_hw=(640, 480), frame_dtype=torch.float16, graph=True, pool=1,
+                 wire=False, **engine_kw):
         engine_cls = PoseEngine if engine_cls is None else engine_cls
         self.depth = max(1, int(depth))
-        engine_kw.setdefault("private_ctx", self.depth > 1)
+        self.pool = max(1, int(pool))
+        engine_kw["private_ctx"] = True
         self.engines = [engine_cls(**engine_kw) for _ in range(self.depth)]
         e0 = self.engines[0]
         self.device, self.max_batch = e0.device, e0.max_batch
         item = e0.frames.shape[1]
-        self.inputs = [torch.zeros((self.max_batch,) + tuple(frame_hw), device=self.device, dtype=frame_dtype) for _ in range(self.depth)]
+        self.wire = bool(wire) and isinstance(e0, PoseEngine)
+        hitem = _lib.POSE_WIRE_DTYPE.itemsize if self.wire else item
+        self.inputs = [[torch.zeros((self.max_batch,) + tuple(frame_hw), device=self.device, dtype=frame_dtype)
+                        for _ in range(self.pool)] for _ in range(self.depth)]
         self.recs = [torch.empty((self.max_batch, item), device=self.device, dtype=torch.uint8) for _ in range(self.depth)]
-        self.host = [torch.empty((self.max_batch, item), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+        self.wires = [torch.empty((self.max_batch, hitem), device=self.device, dtype=torch.uint8) if self.wire else None
+                      for _ in range(self.depth)]
+        self.host = [torch.empty((self.max_batch, hitem), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.events = [torch.cuda.Event() for _ in range(self.depth)]
-        self.graphs = [None] * self.depth
+        self.graphs = [[None] * self.pool for _ in range(self.depth)]
         self._want_graph = bool(graph)
         self._tickets = 0
         cur = torch.cuda.current_stream(self.device)
         for st in self.streams:
             st.wait_stream(cur)
 
-    def input(self, slot):
-        return self.inputs[slot % self.depth]
+    def input(self, slot, j=0):
+        return self.inputs[slot % self.depth][j % self.pool]
 
     def stream(self, slot):
         return self.streams[slot % self.depth]
 
-    def _body(self, s):
-        self.engines[s].predict(self.inputs[s], self.recs[s])
-        self.host[s].copy_(self.recs[s], non_blocking=True)
+    def _body(self, s, j=0):
+        e = self.engines[s]
+        e.predict(self.inputs[s][j], self.recs[s])
+        if self.wire:
+            e.pack(self.recs[s], self.wires[s])
+            self.host[s].copy_(self.wires[s], non_blocking=True)
+        else:
+            self.host[s].copy_(self.recs[s], non_blocking=True)
 
     def capture(self):
-        """Warm every slot eagerly, then record its step as one hipGraph (same kernels, same arguments)."""
+        """Warm every slot eagerly, lock its net, then record its step as one hipGraph per input buffer (same kernels,
+        same arguments)."""
         for s in range(self.depth):
             with torch.cuda.stream(self.streams[s]):
                 self._body(s)
                 self._body(s)
             torch.cuda.synchronize(self.device)
+            self.engines[s].lock()
             if self._want_graph:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.streams[s]):
-                    self._body(s)
-                self.graphs[s] = g
+                for j in range(self.pool):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.streams[s]):
+                        self._body(s, j)
+                    self.graphs[s][j] = g
         torch.cuda.synchronize(self.device)
 
-    def submit(self, eager=False):
-        """Runs the next slot on its stream (asynchronous).  Returns the ticket."""
+    def submit(self, j=0, eager=False):
+        """Runs the next slot on input buffer j of that slot, on the slot's stream (asynchronous).  Returns the ticket."""
         t = self._tickets
         s = t % self.depth
+        j %= self.pool
         with torch.cuda.stream(self.streams[s]):
-            if self.graphs[s] is not None and not eager:
-                self.graphs[s].replay()
+            if self.graphs[s][j] is not None and not eager:
+                self.graphs[s][j].replay()
             else:
-                self._body(s)
+                self._body(s, j)
             self.events[s].record(self.streams[s])
         self._tickets += 1
         return t
@@ -293,7 +331,10 @@ def wire_to_lists(wire):
     """pn_pose_wire records (numpy) -> the per-frame result-schema entries (float32 values widened to Python floats)."""
     out = {"human_pred_set_2d": [], "human_pred_set_3d": [], "human_pred_set_visibility": [], "human_pred_set_part_conf": []}
     for fr in wire:
-        n = min(int(fr["n_persons"]), _lib.PN_WIRE_MAX_PERSONS)
+        if int(fr["status"]):        # peak / person overflow, or more persons than the wire form carries: never truncate silently
+            raise _lib.PopnetError("pose wire record overflow (status=%d, %d persons; the wire form carries %d): use the full pn_pose_frame records"
+                                   % (int(fr["status"]), int(fr["n_persons"]), _lib.PN_WIRE_MAX_PERSONS))
+        n = int(fr["n_persons"])
         v = fr["vals"][:n].astype(np.float64)
         out["human_pred_set_2d"].append(v[:, :, 0:2].tolist())
         out["human_pred_set_3d"].append(v[:, :, 2:5].tolist())

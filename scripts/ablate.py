@@ -10,7 +10,7 @@ eng = PoseEngine(precision="bf16", device="cuda:0", max_batch=32)
 if os.environ.get("POPNET_ZERO_W"):
     with torch.no_grad():
         for p_ in eng.model.parameters(): p_.zero_()
-    eng.model.invalidate(); eng.net = eng.model._compile(eng.device, 32, 224, 224)
+    eng.model.invalidate()     # the engine re-reads the handle (PoseEngine.net)
 d = torch.from_numpy(synth.synth_depth(32)).cuda()
 B = eng.preprocess(d)
 for _ in range(5): eng.forward(B)

@@ -33,7 +33,14 @@ def main(argv=None):
     ap.add_argument("--drop-last", action="store_true", help="skip the tail like the reference's drop_last=True loader")
     ap.add_argument("--no-metrics", action="store_true")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (StreamingEngine); 1 = plain sequential engine")
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to shard the frames over: from a bare shell the script starts that many ranks itself")
     args = ap.parse_args(argv)
+
+    import popnet_amd  # noqa: F401
+    from popnet_amd import launch                                   # touches no GPU
+    if args.gpus > 1 and not launch.under_torchrun():
+        # become the parent of N fresh ranks before any HIP call; they run this same script with the same arguments
+        sys.exit(launch.relaunch(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -94,3 +94,28 @@ def test_sharded_dataset_sweep_world2_gloo(tmp_path):
     port = 29700 + (os.getpid() % 1000)
     mp.spawn(_sweep_worker, args=(2, str(tmp_path), n_frames, port, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_bench_self_launches_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver starts it) must start two fresh
+    ranks itself before touching a GPU and relay rank 0's single JSON line; the dry-run flag swaps the GPU work for a
+    gloo all-reduce so the launcher path runs on the CPU box."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launcher-dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["launcher_dry_run"] and out["n_gpus"] == 2 and out["rank_sum"] == 3
+
+
+def test_torchrun_command_shape():
+    import popnet_amd  # noqa: F401
+    from popnet_amd import launch
+    cmd = launch.torchrun_command("bench.py", ["--gpus", "4"], 4, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-3:] == ["bench.py", "--gpus", "4"]
