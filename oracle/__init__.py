@@ -18,5 +18,19 @@ Pinning status (see DESIGN.md "Oracle"):
     reference's environment.yaml:325) is a third-party dependency absent from
     both ``/root/reference`` and this image.  ``oracle/cv2_resize.py`` restates its
     published algorithm; it is cross-checked against ``torch.nn.functional
-    .interpolate`` (same kernel, different evaluation order) only.
+    .interpolate`` (same kernel, different evaluation order) and pinned by hand-derived
+    known answers (``tests/test_cv2_kat.py``: an exact-rational evaluator that follows the
+    scalar code path of resize.cpp operation by operation and rounds every float32 operation
+    itself, plus frozen hex answers and analytic properties of the A = -0.75 kernel).
+    What can still move the LAST ULP against a real OpenCV build, and is therefore not claimed
+    (none of it can be checked here; these are the known degrees of freedom of resize.cpp builds):
+      - SIMD code paths compiled with FMA (the AVX2 / AVX-512 dispatch of the ``VResize*Vec_32f`` /
+        ``HResize*`` helpers): a fused multiply-add skips the rounding of a product that the
+        scalar path performs;
+      - a SIMD vertical pass is free to associate the four (cubic) row products differently from
+        the scalar left-to-right sum;
+      - vendor back ends a wheel may be built with (IPP on x86) whose float results are not
+        specified bit for bit;
+      - INTER_LINEAR at exactly 2x decimation runs INTER_AREA (ResizeAreaFast): refused by the
+        oracle and by ``pn_preprocess`` instead of guessed.
 """

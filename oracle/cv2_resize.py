@@ -108,6 +108,11 @@ def resize(src, dsize=None, fx=0.0, fy=0.0, interpolation=INTER_LINEAR):
         dw, dh = int(dsize[0]), int(dsize[1])
         inv_x, inv_y = dw / sw, dh / sh
     scale_x, scale_y = 1.0 / inv_x, 1.0 / inv_y
+    if interpolation == INTER_LINEAR and scale_x == 2.0 and scale_y == 2.0:
+        # resize.cpp (4.2): "if (is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA" -- the exact
+        # 2x decimation runs ResizeAreaFast, whose SIMD body ((a+b)+(c+d))*0.25 and scalar tail (((a+b)+c)+d)*0.25
+        # associate the four taps differently; which pixels take which depends on the build's SIMD width.  Not restated.
+        raise NotImplementedError("cv2.resize INTER_LINEAR at exactly 2x decimation switches to INTER_AREA: not modelled")
 
     if interpolation == INTER_NEAREST:
         xs = np.minimum(np.floor(np.arange(dw) * (1.0 / inv_x)).astype(np.int64), sw - 1)

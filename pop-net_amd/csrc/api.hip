@@ -98,6 +98,8 @@ int pn_preprocess(pn_ctx *ctx, const void *depth_dev, int depth_dtype, int B, in
     if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
     if (!depth_dev || !out_dev || B < 1 || H < 2 || W < 2 || S < 1)
         return pn_set_error(ctx, PN_ERR_INVALID, "pn_preprocess: bad arguments");
+    if (W == 2 * S && H == 2 * S)   // cv::resize (4.2 resize.cpp) switches INTER_LINEAR to INTER_AREA at exactly 2x decimation: that branch is not built
+        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_preprocess: %dx%d -> %d is an exact 2x decimation, where cv2.resize(INTER_LINEAR) runs INTER_AREA instead: not built", W, H, S);
     const double inv_x = (double)S / (double)W, inv_y = (double)S / (double)H;
     const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;   // as cv::resize computes them
     if (B > 65535 || (size_t)S * S > 0x7fffffffu) return pn_set_error(ctx, PN_ERR_INVALID, "pn_preprocess: batch or output size out of range");

@@ -29,6 +29,7 @@ int pn_launch_conv_part3(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
     int rc;
+    if (L.kern == 4) return pn_launch_conv4(ctx, L, stream);
     if (L.kern == 3) return pn_launch_conv3(ctx, L, stream);
     if ((rc = pn_launch_conv_part0(ctx, L, stream)) != 1) return rc;
     if ((rc = pn_launch_conv_part1(ctx, L, stream)) != 1) return rc;

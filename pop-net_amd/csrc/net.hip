@@ -49,6 +49,7 @@ struct ConvSpec {
     int cfg = 0, pitch = 0, R = 0, Wt = 0, cin_chunks = 0;
     int kern = 0, wc = 0, wp = 0, nbuf = 0, pt = 7, rpg = 4;   // kern 3: conv3_kernel<ks, wc, wp, nbuf, pt, rpg> (bf16, stride 1, strip tiles)
     int wc_min = 0, nbuf_min = 0;             // set by harmonize_level: share the launch of a wider sibling conv
+    int k4_level = 0;                         // set by harmonize_level: a 3x3 conv of this level has Cin >= 128 and >= 64 couts (conv4_kernel)
     void *wpack = nullptr;
     float *bias = nullptr;
     double flops = 0;
@@ -221,18 +222,41 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
             cs.nbuf = ((cs.cin_chunks > 1 || cs.nbuf_min == 2) && ks == 3 && ngw <= 18 && getenv("POPNET_CONV3_NBUF2")) ? 2 : 1;
             cs.Wt = wt;
             cs.R = std::min(ib0.H, rows * cs.wp * (cs.pt / 7));          // rows * Wt <= 112 (224) pixel slots per wave group
+            // conv4_kernel (both operands through LDS, 64-cout x 112-pixel wave tiles): the 3x3 layers with Cin >= 128 and
+            // >= 64 couts on 4-row strip tiles; a Cin = 64 conv joins only as the sibling of such a layer (one launch per level)
+            if (ks == 3 && cs.wp == 1 && cs.pt == 7 && cs.rpg == 4 && cout >= 64 && (cs.cin_chunks >= 2 || cs.k4_level) &&
+                !getenv("POPNET_NO_CONV4"))
+                cs.kern = 4;
         }
     }
-    const int BC = cs.kern == 3 ? cs.wc * 32 : pn_cfg_couts(cs.cfg);
+    const int BC = cs.kern == 4 ? 128 : (cs.kern == 3 ? cs.wc * 32 : pn_cfg_couts(cs.cfg));
     const int cout_pad = (cout + BC - 1) / BC * BC;
     const int ctiles = cout_pad / 16;
     const int KK = ks * ks;
     const int ksteps = cs.cin_chunks * KK * 2;
     const size_t fragb = n->prec == PN_PREC_BF16 ? 1024 : 2048;
-    const size_t bytes = (size_t)ctiles * ksteps * fragb + 5 * fragb;   // + spare fragments (the weight queue prefetches up to 5 k-steps ahead)
+    const size_t bytes = cs.kern == 4 ? (size_t)(cout_pad / 128) * (ksteps + 3) * 8192      // conv4: [cout block][k-step (+3 spare)][8 tiles][lane][8]
+                                      : (size_t)ctiles * ksteps * fragb + 5 * fragb;   // + spare fragments (the weight queue prefetches up to 5 k-steps ahead)
     std::vector<unsigned char> host(bytes, 0);
     uint16_t *h16 = reinterpret_cast<uint16_t *>(host.data());
     float *h32 = reinterpret_cast<float *>(host.data());
+    if (cs.kern == 4) {
+        for (int cbk = 0; cbk < cout_pad / 128; ++cbk)
+            for (int hh = 0; hh < cs.cin_chunks * 2; ++hh)
+                for (int tap = 0; tap < KK; ++tap)
+                    for (int t = 0; t < 8; ++t)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = cbk * 128 + pn_conv_row_channel(t, lane & 15, 4), q = lane >> 4;
+                            const size_t base = ((((size_t)cbk * (ksteps + 3) + (size_t)hh * KK + tap) * 8 + t) * 64 + lane) * 8;
+                            for (int j = 0; j < 8; ++j) {
+                                const int ci = map[hh * 32 + 8 * q + j];
+                                float v = 0.f;
+                                if (co < cout && ci >= 0)
+                                    v = (float)((double)w->data[((size_t)co * cin_ref + ci) * KK + tap] * scale[co]);
+                                h16[base + j] = f32_to_bf16(v);
+                            }
+                        }
+    } else
     for (int ct = 0; ct < ctiles; ++ct)
         for (int chunk = 0; chunk < cs.cin_chunks; ++chunk)
             for (int sub = 0; sub < 2; ++sub)
@@ -261,7 +285,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     // geometry
     const Buf &ib = n->bufs[cs.in_buf];
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
-    if (cs.kern == 3) {
+    if (cs.kern == 3 || cs.kern == 4) {
         cs.pitch = 32;
         cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
         if (cs.out_buf >= 0) {
@@ -310,6 +334,16 @@ int add_conv(pn_net *n, const std::string &w, const std::string &bn, int ks, int
 // to a wider sibling of the same kernel size takes the sibling's 128-cout block (its two surplus waves only
 // help with the halo DMA, conv3_kernel.h) and the double-buffered variant -- one launch instead of two.
 void harmonize_level(pn_net *n, const std::vector<int> &ids) {
+    {
+        bool k4 = false;
+        for (int id : ids) {
+            const ConvSpec &c = n->convs[id];
+            const HostTensor *w = find_t(n, c.w + ".weight");
+            if (w && w->shape.size() == 4 && c.ks == 3 && c.stride == 1 && w->shape[0] >= 64 && std::max<int64_t>(w->shape[1], (int64_t)c.cin_map.size()) > 64) k4 = true;
+        }
+        if (k4)
+            for (int id : ids) n->convs[id].k4_level = 1;
+    }
     for (int ks : {1, 3}) {
         bool wide = false, multi = false;
         for (int id : ids) {
@@ -341,7 +375,7 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
             if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
-                (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg)) {
+                (a.kern == 4 || (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg))) {
                 st.conv_ids.push_back(ids[j]);
                 used[j] = true;
             }
@@ -541,7 +575,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
     for (auto &st : n->steps) {
         if (st.type != Step::CONV) continue;
         const ConvSpec &c0 = n->convs[st.conv_ids[0]];
-        const int BC = c0.kern == 3 ? c0.wc * 32 : pn_cfg_couts(c0.cfg);
+        const int BC = c0.kern == 4 ? 128 : (c0.kern == 3 ? c0.wc * 32 : pn_cfg_couts(c0.cfg));
         st.host_probs.clear();
         int max_blocks = 0;
         bool two_bufs = false;
@@ -572,6 +606,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.tiles_per_img = ((P.Ho + cs.R - 1) / cs.R) * P.tiles_x;
             P.cout_blocks = (cs.cout + BC - 1) / BC;
             P.nblocks = B * P.tiles_per_img * P.cout_blocks;
+            if (cs.kern == 4) P.nblocks = ((B * P.tiles_per_img + 1) / 2) * P.cout_blocks;      // a block = two strips x 128 couts
             P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
             P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
             P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
@@ -587,6 +622,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R) * (two_bufs ? 2 : 1);
         st.launch.kern = c0.kern; st.launch.wc = c0.wc; st.launch.wp = c0.wp; st.launch.nbuf = c0.nbuf; st.launch.pt = c0.pt; st.launch.rpg = c0.rpg;
         if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf, c0.rpg);
+        if (c0.kern == 4) st.launch.lds_bytes = 0;                        // conv4_launch knows its own size
         st.launch.probs_dev = st.dev_probs;
         PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),
                                             hipMemcpyHostToDevice, stream));
@@ -625,7 +661,8 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
                 for (int id : st.conv_ids) pr->flops += n->convs[id].flops * B;
                 char lb[96];
                 const ConvLaunch &cl = st.launch;
-                if (cl.kern == 3) snprintf(lb, sizeof lb, "conv3_kernel<%d, %d, %d, %d, %d, %d>", cl.ks, cl.wc, cl.wp, cl.nbuf, cl.pt, cl.rpg);
+                if (cl.kern == 4) snprintf(lb, sizeof lb, "conv4_kernel");
+                else if (cl.kern == 3) snprintf(lb, sizeof lb, "conv3_kernel<%d, %d, %d, %d, %d, %d>", cl.ks, cl.wc, cl.wp, cl.nbuf, cl.pt, cl.rpg);
                 else snprintf(lb, sizeof lb, "conv_mfma_kernel<%d, %d, %d, %d, %d>", cl.prec, cl.ks, cl.stride, cl.pitch, cl.cfg);
                 pr->label = lb;
             }
@@ -697,7 +734,7 @@ int pn_net_finalize(pn_net *n, int precision, int max_batch, int in_h, int in_w)
     int rc = n->kind == PN_NET_RTPOSE_LIGHT3D ? build_rtpose(n) : build_yolo(n);
     if (rc) return rc;
     for (auto &b : n->bufs) {
-        size_t bytes = (size_t)max_batch * b.H * b.W * b.C * n->esize() + 256;   // + zero page (halo padding source of conv3_kernel)
+        size_t bytes = (size_t)max_batch * b.H * b.W * b.C * n->esize() + 2048;   // + zero page (halo padding source of conv3_kernel / conv4_kernel: 64 B per 32-channel half + 16)
         if (bytes >= ((size_t)1 << 32))     // the kernels address a buffer with 32-bit byte offsets (zero page, epilogue stores)
             return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "activation buffer %dx%dx%d x batch %d = %zu B exceeds the 4 GiB the kernels' 32-bit offsets address; lower max_batch", b.H, b.W, b.C, max_batch, bytes);
         if (int r = dev_alloc(n, &b.p, bytes, true)) return r;   // zero: pad channels must read as 0

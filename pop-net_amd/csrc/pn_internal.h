@@ -101,6 +101,7 @@ struct ConvLaunch {
 };
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 int pn_launch_conv3(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);     // conv3_inst_*.hip
+int pn_launch_conv4(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);     // conv4_inst.hip
 size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf, int rpg = 4);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
 int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 0 = no limit (direct staging)
