@@ -101,6 +101,34 @@ def mpaug_parse_leg(engine, reps=20):
     return out
 
 
+def precision_modes_leg(dev, steps=30):
+    """north_star's tolerance (1e-3 m, identical assignment) per precision mode, next to what each mode costs: every mode
+    against the fp32 engine on 96 frames of this workload at both synthetic weight sets (popnet_amd.fidelity), and the
+    single-engine, un-pipelined frames/s of the same eager loop in every mode (so the ratios compare like with like)."""
+    from popnet_amd import synth
+    from popnet_amd.fidelity import compare_engines
+    from popnet_amd.pipeline import PoseEngine
+    out = {}
+    depth = torch.from_numpy(synth.synth_depth(BATCH, 640, 480, seed=77)).to(dev)
+    ref = {g: PoseEngine(precision="fp32", device=dev, max_batch=BATCH, calib_gain=g) for g in (1.0, 6.0)}
+    for prec in ("fp32", "bf16x3", "bf16"):
+        eng = {g: (ref[g] if prec == "fp32" else PoseEngine(precision=prec, device=dev, max_batch=BATCH, calib_gain=g)) for g in (1.0, 6.0)}
+        e = eng[1.0]
+        for _ in range(3):
+            e.predict(depth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.predict(depth)
+        torch.cuda.synchronize()
+        rec = {"frames_per_s_one_engine_eager": round(steps * BATCH / (time.perf_counter() - t0), 1)}
+        if prec != "fp32":
+            rec["vs_fp32_threshold_calibrated_weights"] = compare_engines(ref[1.0], eng[1.0], 96)
+            rec["vs_fp32_separated_weights"] = compare_engines(ref[6.0], eng[6.0], 96)
+        out[prec] = rec
+    return out
+
+
 def launcher_dry_run(args):
     """CPU check of the self-launch path: every rank joins a gloo group, rank 0 prints one JSON line."""
     import torch.distributed as dist
@@ -349,6 +377,7 @@ def main():
                                     "what": "same region, every batch copied from pinned host memory on its slot's stream inside the region (%.1f MB per step over PCIe): first H2D enqueue to last record on host, median of %d" % (BATCH * 640 * 480 * 2 / 1e6, REPS)}
         if world == 1 and args.net == "rtpose" and not args.no_extras:
             out["mpaug_parse"] = mpaug_parse_leg(engine)
+            out["precision_modes"] = precision_modes_leg(dev)
         if world == 1 and not args.no_cpu_baseline and args.net == "rtpose":
             out["cpu_baseline"] = cpu_baseline(engine, depth_host)
         print(json.dumps(out))

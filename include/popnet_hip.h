@@ -37,7 +37,10 @@ enum pn_status {
 /* ---- compute / storage precision of the conv stack ---------------------------------------- */
 enum pn_precision {
     PN_PREC_F32 = 0,   /* fp32 storage, fp32-input MFMA (v_mfma_f32_16x16x4_f32): parity mode */
-    PN_PREC_BF16 = 1   /* bf16 storage, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate */
+    PN_PREC_BF16 = 1,  /* bf16 storage, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate: throughput mode */
+    PN_PREC_BF16X3 = 2 /* split-bf16 ("3 x bf16"): every tensor and weight is kept as hi + lo bf16
+                          parts (16 significant bits), a product is x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix
+                          cores with fp32 accumulation; fp32-class results (north_star's 1e-3 m) at ~1/3 of the bf16 rate */
 };
 
 enum pn_net_kind {

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpopnet_hip.so")
 
 PN_OK = 0
-PN_PREC_F32, PN_PREC_BF16 = 0, 1
+PN_PREC_F32, PN_PREC_BF16, PN_PREC_BF16X3 = 0, 1, 2
 PN_NET_RTPOSE_LIGHT3D, PN_NET_YOLO_POSENET = 0, 1
 PN_DEPTH_F16, PN_DEPTH_F32 = 0, 1
 

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     PN_GLOBAL T *out_base = P.out ? (PN_GLOBAL T *)P.out + P.out_coff + cw : nullptr;
     PN_GLOBAL float *nchw = (PN_GLOBAL float *)P.out_nchw;
     const int res_cs = P.res_cs, out_cs = P.out_cs, Ho = P.Ho, naf = P.yolo_naf;
+    const int split = P.split, res_split = P.res_split;
     const int pix0 = (b * Ho + oy0) * Wo + ox0;
     auto finish = [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[4 * ct + i] = acc[ct][pt][i] + bias[4 * ct + i];
-            if (res_base) {
-                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * res_cs);
+            for (int pl = 0; pl < (res_base ? (res_split ? 2 : 1) : 0); ++pl) {      // bf16x3: residual = hi plane + lo plane
+                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * res_cs + pl * res_split);
                 if (full) {
                     T rv[LC];
                     *reinterpret_cast<u32x4 *>(rv) = *reinterpret_cast<const PN_GLOBAL u32x4 *>(rp);
@@ -335,19 +336,25 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
                 else v[k] = pn_activate(v[k], act, cw + k, naf);
             }
             if (out_base) {
-                PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs);
-                if (full) {
+                // bf16x3: three planes [hi | lo | hi] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
+                for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+                    PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs + pl * split);
                     T ov[LC];
 #pragma unroll
-                    for (int k = 0; k < LC; ++k) ov[k] = (T)v[k];
+                    for (int k = 0; k < LC; ++k) {
+                        const T hi = (T)v[k];
+                        ov[k] = pl == 1 ? (T)(v[k] - (float)hi) : hi;
+                    }
+                    if (full) {
 #ifdef PN_CONV3_NT_STORE
-                    __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(ov), reinterpret_cast<PN_GLOBAL u32x4 *>(op));
+                        __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(ov), reinterpret_cast<PN_GLOBAL u32x4 *>(op));
 #else
-                    *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
+                        *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
 #endif
-                } else {
-                    for (int k = 0; k < LC; ++k)
-                        if (cw + k < cout) op[k] = (T)v[k];
+                    } else {
+                        for (int k = 0; k < LC; ++k)
+                            if (cw + k < cout) op[k] = ov[k];
+                    }
                 }
             }
             if (nchw) {
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     // so the results are bit-identical (tests: conv3 == generic kernel).
     const int wave_c0 = (cb * WC + wc) * (CT * 16);
     const bool fast = (PN_CONV3_FAST_EPILOGUE == 1 || (PN_CONV3_FAST_EPILOGUE == 2 && WC == 4)) &&
-                      wave_c0 + CT * 16 <= cout && P.out && !nchw && (act == PN_ACT_RELU || act == PN_ACT_LEAKY || act == PN_ACT_NONE);
+                      wave_c0 + CT * 16 <= cout && P.out && !nchw && !split && !res_split && (act == PN_ACT_RELU || act == PN_ACT_LEAKY || act == PN_ACT_NONE);
     auto finish_fast = [&](auto actc, auto resc) {
         constexpr int ACT = decltype(actc)::value;
         constexpr bool RES = decltype(resc)::value;

@@ -143,12 +143,19 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
 
     // item j = (phase ph, pixel tile pt): B fragment of tap ph % 9 from image (ph / 9) & 1
 #define PN4_BOFF(j) (((((j) / PT) / KK) & 1) * PN4_BBUF + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 64)
-    bf16x8 aq[2][CT], bq[3];
+    // B fragments are read BQ - 1 items (4 MFMAs each) ahead of their use: with 2 ahead a lone wave on its SIMD spent
+    // 147 of 717 cycles per k-step waiting for LDS (profiles/README.md, conv4 ablations)
+#ifndef PN4_BQ
+#define PN4_BQ 6
+#endif
+    constexpr int BQ = PN4_BQ;
+    static_assert((2 * KK * PT) % BQ == 0, "queue slot of an item must not depend on the chunk");
+    bf16x8 aq[2][CT], bq[BQ];
     if (active) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) aq[0][ct] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ct * 1024);
-        bq[0] = *reinterpret_cast<const bf16x8 *>(smem + baddr[0] + PN4_BOFF(0));
-        bq[1] = *reinterpret_cast<const bf16x8 *>(smem + baddr[1] + PN4_BOFF(1));
+#pragma unroll
+        for (int j = 0; j < BQ - 1; ++j) bq[j] = *reinterpret_cast<const bf16x8 *>(smem + baddr[j % PT] + PN4_BOFF(j));
     }
     // phase 0 refills ring slot 0: every wave's reads of k-step 0's fragments must have returned first
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -162,20 +169,26 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                 const int tap = ph % KK, half = ph / KK;
                 const int hh = chunk * 2 + half;
                 // (1) staging for later steps: one halo piece of the NEXT half (taps 0..5), the weight fragments of step s + 3
+#ifndef PN4_FAKE_NODMA_B                        // -DPN4_FAKE_*: timing-only ablations (wrong results), scripts/conv4lab.hip
                 if (tap < 6) dma_b(tap, (half + 1) & 1, hh + 1);
+#endif
+#ifndef PN4_FAKE_NODMA_A
                 dma_a(ph % 3);
+#endif
                 // (2) this step's 28 MFMAs; fragment reads for the next step / the next items between them
                 if (MATH) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
                     for (int pt = 0; pt < PT; ++pt) {
-                        const int j = ph * PT + pt, jr = j + 2;
+                        const int j = ph * PT + pt, jr = j + BQ - 1;
+#ifndef PN4_FAKE_NOLDS
                         if (pt < CT)
                             aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % 3) * PN4_ASLOT + pt * 1024);
-                        bq[jr % 3] = *reinterpret_cast<const bf16x8 *>(smem + baddr[jr % PT] + PN4_BOFF(jr % (2 * KK * PT)));
+                        bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + baddr[jr % PT] + PN4_BOFF(jr % (2 * KK * PT)));
+#endif
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ph & 1][ct], bq[j % 3], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ph & 1][ct], bq[j % BQ], acc[ct][pt], 0, 0, 0);
                         if (pt < CT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                         else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
@@ -184,8 +197,14 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                 }
                 // (3) everything older than the newest weight step (and this phase's halo piece) has landed; every fragment
                 // read issued so far has returned (the slot / image it came from may be overwritten after the barrier)
+#if defined(PN4_FAKE_NOBAR)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif defined(PN4_FAKE_NODMA_A) || defined(PN4_FAKE_NODMA_B)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
                 if (tap < 6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             }
             PN_STAMP_AT(3 + 2 * (chunk & 3));
         }
@@ -211,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
         bias[4 * ct + 0] = b4[0]; bias[4 * ct + 1] = b4[1]; bias[4 * ct + 2] = b4[2]; bias[4 * ct + 3] = b4[3];
     }
     const int res_cs = P.res_cs, out_cs = P.out_cs, Ho = P.Ho;
+    const int split = P.split, res_split = P.res_split;
     const unsigned pix0 = (unsigned)((b * Ho + oy0) * Wo + ox0);
     const bool full = wave_c0 + 64 <= cout && P.out && !P.out_nchw;
     if (full) {
@@ -230,12 +250,14 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[4 * ct + i] = acc[ct][pt][i] + bias[4 * ct + i];
                 if (RES) {
-                    T rv[LC];
-                    const PN_GLOBAL u32x4 *rp = reinterpret_cast<const PN_GLOBAL u32x4 *>(rb + opix * (unsigned)res_cs);
-                    reinterpret_cast<u32x4 *>(rv)[0] = rp[0];
-                    reinterpret_cast<u32x4 *>(rv)[1] = rp[1];
+                    for (int pl = 0; pl < (res_split ? 2 : 1); ++pl) {       // bf16x3: residual = hi plane + lo plane
+                        T rv[LC];
+                        const PN_GLOBAL u32x4 *rp = reinterpret_cast<const PN_GLOBAL u32x4 *>(rb + (opix * (unsigned)res_cs + (unsigned)(pl * res_split)));
+                        reinterpret_cast<u32x4 *>(rv)[0] = rp[0];
+                        reinterpret_cast<u32x4 *>(rv)[1] = rp[1];
 #pragma unroll
-                    for (int k = 0; k < LC; ++k) v[k] += (float)rv[k];
+                        for (int k = 0; k < LC; ++k) v[k] += (float)rv[k];
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < LC; ++k) {
@@ -243,13 +265,19 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                     else if (ACT == PN_ACT_LEAKY) v[k] = v[k] > 0.f ? v[k] : v[k] * 0.1f;
                     else if (ACT != PN_ACT_NONE) v[k] = pn_activate(v[k], act, cw + k, P.yolo_naf);
                 }
-                T ov[LC];
+                // bf16x3: three planes [hi | lo | hi] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
+                for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+                    T ov[LC];
 #pragma unroll
-                for (int k = 0; k < LC; ++k) ov[k] = (T)v[k];
-                if (slot < npix) {
-                    PN_GLOBAL u32x4 *op = reinterpret_cast<PN_GLOBAL u32x4 *>(ob + opix * (unsigned)out_cs);
-                    op[0] = reinterpret_cast<u32x4 *>(ov)[0];
-                    op[1] = reinterpret_cast<u32x4 *>(ov)[1];
+                    for (int k = 0; k < LC; ++k) {
+                        const T hi = (T)v[k];
+                        ov[k] = pl == 1 ? (T)(v[k] - (float)hi) : hi;
+                    }
+                    if (slot < npix) {
+                        PN_GLOBAL u32x4 *op = reinterpret_cast<PN_GLOBAL u32x4 *>(ob + (opix * (unsigned)out_cs + (unsigned)(pl * split)));
+                        op[0] = reinterpret_cast<u32x4 *>(ov)[0];
+                        op[1] = reinterpret_cast<u32x4 *>(ov)[1];
+                    }
                 }
             }
         };
@@ -287,8 +315,16 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                     if (cw + k >= cout) continue;
                     float v = acc[ct][pt][i] + bias[k];
                     if (res_base) v += (float)res_base[opix * (unsigned)res_cs + k];
+                    if (res_base && res_split) v += (float)res_base[opix * (unsigned)res_cs + res_split + k];
                     v = pn_activate(v, act, cw + k, P.yolo_naf);
-                    if (out_base) out_base[opix * (unsigned)out_cs + k] = (T)v;
+                    if (out_base) {
+                        const T hi = (T)v;
+                        out_base[opix * (unsigned)out_cs + k] = hi;
+                        if (split) {
+                            out_base[opix * (unsigned)out_cs + split + k] = (T)(v - (float)hi);
+                            out_base[opix * (unsigned)out_cs + 2 * split + k] = hi;
+                        }
+                    }
                     if (nchw) nchw[((size_t)b * cout + cw + k) * ((size_t)Ho * Wo) + (size_t)(oy0 + ry) * Wo + (ox0 + rx)] = v;
                 }
         }

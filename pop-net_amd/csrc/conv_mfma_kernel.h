@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     PN_GLOBAL T *out_base = P.out ? (PN_GLOBAL T *)P.out + P.out_coff + cw : nullptr;
     PN_GLOBAL float *nchw = (PN_GLOBAL float *)P.out_nchw;
     const int res_cs = P.res_cs, out_cs = P.out_cs, Ho = P.Ho, naf = P.yolo_naf;
+    const int split = P.split, res_split = P.res_split;
     const int pix0 = (b * Ho + oy0) * Wo + ox0;
     auto finish = [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;            // -1: dispatch at run time (sigmoid casts: last layers only)
@@ -443,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[4 * ct + i] = acc[ct][pt][i] + bias[4 * ct + i];
-            if (res_base) {
-                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * res_cs);
+            for (int pl = 0; pl < (res_base ? (res_split ? 2 : 1) : 0); ++pl) {      // bf16x3: residual = hi plane + lo plane
+                const PN_GLOBAL T *rp = res_base + (unsigned)(opix * res_cs + pl * res_split);
                 if (full) {
                     T rv[LC];
                     if (LC * sizeof(T) == 16) {
@@ -471,23 +472,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
                 else v[k] = pn_activate(v[k], act, cw + k, naf);
             }
             if (out_base) {
-                PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs);
-                if (full) {
+                // bf16x3: three planes [hi | lo | hi] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
+                for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+                    PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs + pl * split);
                     T ov[LC];
 #pragma unroll
-                    for (int k = 0; k < LC; ++k) ov[k] = (T)v[k];
-                    if (LC * sizeof(T) == 16) {
-                        *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
-                    } else if (LC * sizeof(T) == 32) {
-                        reinterpret_cast<PN_GLOBAL u32x4 *>(op)[0] = reinterpret_cast<u32x4 *>(ov)[0];
-                        reinterpret_cast<PN_GLOBAL u32x4 *>(op)[1] = reinterpret_cast<u32x4 *>(ov)[1];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < LC; ++k) op[k] = ov[k];
+                    for (int k = 0; k < LC; ++k) {
+                        const T hi = (T)v[k];
+                        ov[k] = pl == 1 ? (T)(v[k] - (float)hi) : hi;
                     }
-                } else {
-                    for (int k = 0; k < LC; ++k)
-                        if (cw + k < cout) op[k] = (T)v[k];
+                    if (full) {
+                        if (LC * sizeof(T) == 16) {
+                            *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(ov);
+                        } else if (LC * sizeof(T) == 32) {
+                            reinterpret_cast<PN_GLOBAL u32x4 *>(op)[0] = reinterpret_cast<u32x4 *>(ov)[0];
+                            reinterpret_cast<PN_GLOBAL u32x4 *>(op)[1] = reinterpret_cast<u32x4 *>(ov)[1];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < LC; ++k) op[k] = ov[k];
+                        }
+                    } else {
+                        for (int k = 0; k < LC; ++k)
+                            if (cw + k < cout) op[k] = ov[k];
+                    }
                 }
             }
             if (nchw) {                                       // API-boundary layout: 16 lanes = 16 consecutive pixels of a plane

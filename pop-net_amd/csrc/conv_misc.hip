@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <typename T>
 __global__ __launch_bounds__(256) void stem7x7_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                        const float *__restrict__ bias, T *__restrict__ out,
-                                                       int H, int W, int Ho, int Wo, int out_cs) {
+                                                       int H, int W, int Ho, int Wo, int out_cs, int split) {
     __shared__ float tile[37][40];
     __shared__ __attribute__((aligned(16))) float wl[49 * 64];
     const int tid = threadIdx.x;
@@ -62,7 +62,13 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
             float v = acc[i] + bias[i];
-            op[i] = (T)(v > 0.f ? v : 0.f);
+            v = v > 0.f ? v : 0.f;
+            const T hi = (T)v;
+            op[i] = hi;
+            if (split) {                                  // bf16x3: planes [hi | lo | hi]
+                op[split + i] = (T)(v - (float)hi);
+                op[2 * split + i] = hi;
+            }
         }
     }
 }
@@ -83,7 +89,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int stem_u32x4;
 
 __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wfrag,
                                                             const float *__restrict__ bias, __bf16 *__restrict__ out,
-                                                            int H, int W, int Ho, int Wo, int out_cs) {
+                                                            int H, int W, int Ho, int Wo, int out_cs, int split) {
     __shared__ __attribute__((aligned(16))) __bf16 tile[38 * STEM_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -122,28 +128,35 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
         }
         const int oy = oy0 + ry, ox = ox0 + c;
         if (oy < Ho && ox < Wo) {
-            __bf16 o[16];
+            // bf16x3: three planes [hi | lo | hi] `split` channels apart (pn_internal.h, ConvProblem::split)
+            for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+                __bf16 o[16];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[t][r] + bs[4 * t + r];
-                    o[4 * t + r] = (__bf16)(v > 0.f ? v : 0.f);
-                }
-            __bf16 *op = out + ((size_t)(b * Ho + oy) * Wo + ox) * out_cs + 16 * q;
-            reinterpret_cast<stem_u32x4 *>(op)[0] = reinterpret_cast<stem_u32x4 *>(o)[0];
-            reinterpret_cast<stem_u32x4 *>(op)[1] = reinterpret_cast<stem_u32x4 *>(o)[1];
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[t][r] + bs[4 * t + r];
+                        v = v > 0.f ? v : 0.f;
+                        const __bf16 hi = (__bf16)v;
+                        o[4 * t + r] = pl == 1 ? (__bf16)(v - (float)hi) : hi;
+                    }
+                __bf16 *op = out + ((size_t)(b * Ho + oy) * Wo + ox) * out_cs + 16 * q + pl * split;
+                reinterpret_cast<stem_u32x4 *>(op)[0] = reinterpret_cast<stem_u32x4 *>(o)[0];
+                reinterpret_cast<stem_u32x4 *>(op)[1] = reinterpret_cast<stem_u32x4 *>(o)[1];
+            }
         }
     }
 }
 
 int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const void *wfrag, const float *bias, void *out,
-                   int B, int H, int W, int Ho, int Wo, int out_cs, hipStream_t stream) {
+                   int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream) {
     dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B), block(256);
     if (prec == PN_PREC_BF16)
-        hipLaunchKernelGGL(stem7x7_mfma_kernel, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs);
+        hipLaunchKernelGGL(stem7x7_mfma_kernel, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
+    else if (prec == PN_PREC_BF16X3)     // exact fp32 stem (the MFMA stem rounds the INPUT frame to bf16), split bf16 output
+        hipLaunchKernelGGL(stem7x7_kernel<__bf16>, grid, block, 0, stream, x, w, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
     else
-        hipLaunchKernelGGL(stem7x7_kernel<float>, grid, block, 0, stream, x, w, bias, (float *)out, H, W, Ho, Wo, out_cs);
+        hipLaunchKernelGGL(stem7x7_kernel<float>, grid, block, 0, stream, x, w, bias, (float *)out, H, W, Ho, Wo, out_cs, 0);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -153,7 +166,7 @@ int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const 
 // ---------------------------------------------------------------------------------------------
 template <typename T, int MODE>
 __global__ void pool_kernel(const T *__restrict__ in, T *__restrict__ out, int B, int H, int W, int Ho, int Wo,
-                            int C8, int in_cs, int out_cs, int out_coff) {
+                            int C8, int in_cs, int out_cs, int out_coff, int in_split, int out_split) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)B * Ho * Wo * C8;
     if (gid >= total) return;
@@ -182,47 +195,61 @@ __global__ void pool_kernel(const T *__restrict__ in, T *__restrict__ out, int B
                 reinterpret_cast<uint4 *>(v)[0] = reinterpret_cast<const uint4 *>(ip)[0];
                 reinterpret_cast<uint4 *>(v)[1] = reinterpret_cast<const uint4 *>(ip)[1];
             }
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+            if (in_split) {                               // bf16x3: value = hi plane + lo plane
+                T v2[8];
+                *reinterpret_cast<uint4 *>(v2) = *reinterpret_cast<const uint4 *>(ip + in_split);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] += (float)v2[i];
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float f = (float)v[i];
-                if (MODE == 0) acc[i] += f;
-                else acc[i] = fmaxf(acc[i], f);
+                if (MODE == 0) acc[i] += f[i];
+                else acc[i] = fmaxf(acc[i], f[i]);
             }
         }
     }
-    T o[8];
+    for (int pl = 0; pl < (out_split ? 3 : 1); ++pl) {      // bf16x3: planes [hi | lo | hi]
+        T o[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (T)((MODE == 0) ? acc[i] / 9.0f : acc[i]);
-    T *op = out + p * out_cs + out_coff + c8 * 8;
-    if (sizeof(T) == 2) {
-        *reinterpret_cast<uint4 *>(op) = *reinterpret_cast<uint4 *>(o);
-    } else {
-        reinterpret_cast<uint4 *>(op)[0] = reinterpret_cast<uint4 *>(o)[0];
-        reinterpret_cast<uint4 *>(op)[1] = reinterpret_cast<uint4 *>(o)[1];
+        for (int i = 0; i < 8; ++i) {
+            const float r = (MODE == 0) ? acc[i] / 9.0f : acc[i];
+            const T hi = (T)r;
+            o[i] = pl == 1 ? (T)(r - (float)hi) : hi;
+        }
+        T *op = out + p * out_cs + out_coff + c8 * 8 + pl * out_split;
+        if (sizeof(T) == 2) {
+            *reinterpret_cast<uint4 *>(op) = *reinterpret_cast<uint4 *>(o);
+        } else {
+            reinterpret_cast<uint4 *>(op)[0] = reinterpret_cast<uint4 *>(o)[0];
+            reinterpret_cast<uint4 *>(op)[1] = reinterpret_cast<uint4 *>(o)[1];
+        }
     }
 }
 
 template <typename T>
 static void launch_pool_t(int mode, const void *in, void *out, int B, int H, int W, int Ho, int Wo, int C,
-                          int in_cs, int out_cs, int out_coff, hipStream_t stream) {
+                          int in_cs, int out_cs, int out_coff, int in_split, int out_split, hipStream_t stream) {
     size_t total = (size_t)B * Ho * Wo * (C / 8);
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (mode == 0)
-        hipLaunchKernelGGL((pool_kernel<T, 0>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff);
+        hipLaunchKernelGGL((pool_kernel<T, 0>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff, in_split, out_split);
     else if (mode == 1)
-        hipLaunchKernelGGL((pool_kernel<T, 1>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff);
+        hipLaunchKernelGGL((pool_kernel<T, 1>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff, in_split, out_split);
     else
-        hipLaunchKernelGGL((pool_kernel<T, 2>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff);
+        hipLaunchKernelGGL((pool_kernel<T, 2>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff, in_split, out_split);
 }
 
 int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, int B, int H, int W, int C,
-                   int in_cs, int out_cs, int out_coff, hipStream_t stream) {
+                   int in_cs, int out_cs, int out_coff, int in_split, int out_split, hipStream_t stream) {
     if (C % 8 || in_cs % 8 || out_cs % 8 || out_coff % 8)
         return pn_set_error(ctx, PN_ERR_INVALID, "pool: channels must be multiples of 8");
     int Ho = (mode == 2) ? H / 2 : (H + 2 - 3) / 2 + 1;
     int Wo = (mode == 2) ? W / 2 : (W + 2 - 3) / 2 + 1;
-    if (prec == PN_PREC_BF16) launch_pool_t<__bf16>(mode, in, out, B, H, W, Ho, Wo, C, in_cs, out_cs, out_coff, stream);
-    else launch_pool_t<float>(mode, in, out, B, H, W, Ho, Wo, C, in_cs, out_cs, out_coff, stream);
+    if (prec == PN_PREC_BF16) launch_pool_t<__bf16>(mode, in, out, B, H, W, Ho, Wo, C, in_cs, out_cs, out_coff, in_split, out_split, stream);
+    else launch_pool_t<float>(mode, in, out, B, H, W, Ho, Wo, C, in_cs, out_cs, out_coff, 0, 0, stream);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -232,7 +259,7 @@ int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, i
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T *__restrict__ in, float *__restrict__ out, int B, int HW, int C,
-                                    int in_cs, int in_coff) {
+                                    int in_cs, int in_coff, int split) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)B * C * HW;
     if (gid >= total) return;
@@ -240,17 +267,19 @@ __global__ void nhwc_to_nchw_kernel(const T *__restrict__ in, float *__restrict_
     size_t t = gid / HW;
     int ch = (int)(t % C);
     int b = (int)(t / C);
-    out[gid] = (float)in[((size_t)b * HW + p) * in_cs + in_coff + ch];
+    float v = (float)in[((size_t)b * HW + p) * in_cs + in_coff + ch];
+    if (split) v += (float)in[((size_t)b * HW + p) * in_cs + in_coff + ch + split];      // bf16x3: hi + lo
+    out[gid] = v;
 }
 
 int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, int B, int H, int W, int C,
-                           int in_cs, int in_coff, hipStream_t stream) {
+                           int in_cs, int in_coff, int split, hipStream_t stream) {
     size_t total = (size_t)B * C * H * W;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (prec == PN_PREC_BF16)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, grid, block, 0, stream, (const __bf16 *)in, out, B, H * W, C, in_cs, in_coff);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, grid, block, 0, stream, (const __bf16 *)in, out, B, H * W, C, in_cs, in_coff, split);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, stream, (const float *)in, out, B, H * W, C, in_cs, in_coff);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, stream, (const float *)in, out, B, H * W, C, in_cs, in_coff, 0);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }

@@ -32,6 +32,7 @@ struct HostTensor {
 struct Buf {
     void *p = nullptr;
     int H = 0, W = 0, C = 0;   // C = channel stride
+    int plane = 0;             // bf16x3: channels of one of the three planes [hi | lo | hi] (C = 3 * plane); otherwise = C
 };
 
 struct ConvSpec {
@@ -92,6 +93,7 @@ struct pn_net {
     std::vector<void *> dev_allocs;
     float *nchw_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_B = -1;
+    bool x3 = false;                 // PN_PREC_BF16X3: tensors stored as [hi | lo | hi] bf16 planes, weights as [W_hi | W_hi | W_lo]
     bool locked = false;             // pn_net_lock: descriptors frozen (a captured hipGraph reads them at replay time)
     float *last_nchw[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<std::string, std::pair<int, std::pair<int, int>>> named;   // name -> (buf, (coff, C))
@@ -133,7 +135,7 @@ int dev_alloc(pn_net *n, void **p, size_t bytes, bool zero) {
 
 int new_buf(pn_net *n, int H, int W, int C) {
     Buf b;
-    b.H = H; b.W = W; b.C = C;
+    b.H = H; b.W = W; b.plane = C; b.C = n->x3 ? 3 * C : C;
     n->bufs.push_back(b);
     return (int)n->bufs.size() - 1;
 }
@@ -170,8 +172,22 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     for (int m : map)
         if (m >= cin_ref)
             return pn_set_error(ctx, PN_ERR_INVALID, "%s: input-channel map exceeds Cin=%d", cs.w.c_str(), cin_ref);
+    std::vector<int> wsel;                        // bf16x3: which half of the split weight multiplies this input channel (0 = hi, 1 = lo)
+    if (n->x3) {
+        // the input is the WHOLE buffer, three planes of `plane` channels: [x_hi | x_lo | x_hi] against [W_hi | W_hi | W_lo]
+        // = x_hi W_hi + x_lo W_hi + x_hi W_lo (the dropped x_lo W_lo term is 2^-16 of the product)
+        const int pc = n->bufs[cs.in_buf].plane;
+        if (cs.in_coff != 0 || (int)map.size() > pc)
+            return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: bf16x3 convolutions read whole buffers", cs.w.c_str());
+        map.resize(pc, -1);
+        std::vector<int> m3;
+        for (int pl = 0; pl < 3; ++pl)
+            for (int i = 0; i < pc; ++i) { m3.push_back(map[i]); wsel.push_back(pl == 2 ? 1 : 0); }
+        map.swap(m3);
+    }
     const int cin_pad = ((int)map.size() + 63) / 64 * 64;
     map.resize(cin_pad, -1);
+    wsel.resize(cin_pad, 0);
     cs.cin_chunks = cin_pad / 64;
     cs.cin = cin_ref;
 
@@ -191,6 +207,17 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
             shift[o] = (shift[o] - (double)mu->data[o]) * s + (double)be->data[o];
         }
     }
+
+    auto wval = [&](int co, int idx, int tap) -> float {      // folded weight of packed input channel idx
+        const int ci = map[idx];
+        if (co >= cout || ci < 0) return 0.f;
+        const float v = (float)((double)w->data[((size_t)co * cin_ref + ci) * (ks * ks) + tap] * scale[co]);
+        if (!n->x3) return v;
+        uint32_t hb = (uint32_t)f32_to_bf16(v) << 16;
+        float hi;
+        memcpy(&hi, &hb, 4);
+        return wsel[idx] ? v - hi : hi;
+    };
 
     cs.cfg = pick_cfg(cout);
     {   // bf16 stride-1 layers run conv3_kernel (conv3_kernel.h) when the map splits into column strips (<= 30 wide: the
@@ -248,13 +275,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
                         for (int lane = 0; lane < 64; ++lane) {
                             const int co = cbk * 128 + pn_conv_row_channel(t, lane & 15, 4), q = lane >> 4;
                             const size_t base = ((((size_t)cbk * (ksteps + 3) + (size_t)hh * KK + tap) * 8 + t) * 64 + lane) * 8;
-                            for (int j = 0; j < 8; ++j) {
-                                const int ci = map[hh * 32 + 8 * q + j];
-                                float v = 0.f;
-                                if (co < cout && ci >= 0)
-                                    v = (float)((double)w->data[((size_t)co * cin_ref + ci) * KK + tap] * scale[co]);
-                                h16[base + j] = f32_to_bf16(v);
-                            }
+                            for (int j = 0; j < 8; ++j) h16[base + j] = f32_to_bf16(wval(co, hh * 32 + 8 * q + j, tap));
                         }
     } else
     for (int ct = 0; ct < ctiles; ++ct)
@@ -266,10 +287,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
                     for (int lane = 0; lane < 64; ++lane) {
                         const int co = pn_conv_row_channel(ct, lane & 15, cs.kern == 3 ? 2 : pn_cfg_ct(cs.cfg)), q = lane >> 4;
                         for (int j = 0; j < 8; ++j) {
-                            const int ci = map[chunk * 64 + sub * 32 + 8 * q + j];
-                            float v = 0.f;
-                            if (co < cout && ci >= 0)
-                                v = (float)((double)w->data[((size_t)co * cin_ref + ci) * KK + tap] * scale[co]);
+                            const float v = wval(co, chunk * 64 + sub * 32 + 8 * q + j, tap);
                             if (n->prec == PN_PREC_BF16) h16[(frag * 64 + lane) * 8 + j] = f32_to_bf16(v);
                             else h32[frag * 512 + (size_t)(j >> 2) * 256 + lane * 4 + (j & 3)] = v;
                         }
@@ -339,7 +357,7 @@ void harmonize_level(pn_net *n, const std::vector<int> &ids) {
         for (int id : ids) {
             const ConvSpec &c = n->convs[id];
             const HostTensor *w = find_t(n, c.w + ".weight");
-            if (w && w->shape.size() == 4 && c.ks == 3 && c.stride == 1 && w->shape[0] >= 64 && std::max<int64_t>(w->shape[1], (int64_t)c.cin_map.size()) > 64) k4 = true;
+            if (w && w->shape.size() == 4 && c.ks == 3 && c.stride == 1 && w->shape[0] >= 64 && (n->x3 || std::max<int64_t>(w->shape[1], (int64_t)c.cin_map.size()) > 64)) k4 = true;
         }
         if (k4)
             for (int id : ids) n->convs[id].k4_level = 1;
@@ -595,8 +613,8 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.cin_chunks = cs.cin_chunks;
             P.in_cs = ib.C; P.in_coff = cs.in_coff;
             P.cout = cs.cout;
-            if (cs.out_buf >= 0) { P.out = n->bufs[cs.out_buf].p; P.out_cs = n->bufs[cs.out_buf].C; P.out_coff = cs.out_coff; }
-            if (cs.res_buf >= 0) { P.res = n->bufs[cs.res_buf].p; P.res_cs = n->bufs[cs.res_buf].C; P.res_coff = cs.res_coff; }
+            if (cs.out_buf >= 0) { P.out = n->bufs[cs.out_buf].p; P.out_cs = n->bufs[cs.out_buf].C; P.out_coff = cs.out_coff; P.split = n->x3 ? n->bufs[cs.out_buf].plane : 0; }
+            if (cs.res_buf >= 0) { P.res = n->bufs[cs.res_buf].p; P.res_cs = n->bufs[cs.res_buf].C; P.res_coff = cs.res_coff; P.res_split = n->x3 ? n->bufs[cs.res_buf].plane : 0; }
             if (cs.nchw_slot >= 0) P.out_nchw = n->nchw_ptr[cs.nchw_slot];
             P.act = cs.act;
             P.yolo_naf = 5 + 3 * n->num_parts;
@@ -670,10 +688,10 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         }
         if (st.type == Step::STEM) {
             const Buf &ob = n->bufs[st.out_buf];
-            rc = pn_launch_stem(ctx, n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, stream);
+            rc = pn_launch_stem(ctx, n->x3 ? PN_PREC_BF16X3 : n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, n->x3 ? ob.plane : 0, stream);
         } else if (st.type == Step::POOL) {
             const Buf &ib = n->bufs[st.in_buf], &ob = n->bufs[st.out_buf];
-            rc = pn_launch_pool(ctx, n->prec, st.mode, ib.p, ob.p, B, ib.H, ib.W, st.C, ib.C, ob.C, st.out_coff, stream);
+            rc = pn_launch_pool(ctx, n->prec, st.mode, ib.p, ob.p, B, ib.H, ib.W, st.C, ib.C, ob.C, st.out_coff, n->x3 ? ib.plane : 0, n->x3 ? ob.plane : 0, stream);
         } else {
             rc = pn_launch_conv(ctx, st.launch, stream);
         }
@@ -727,10 +745,11 @@ int pn_net_finalize(pn_net *n, int precision, int max_batch, int in_h, int in_w)
     if (!n) return PN_ERR_INVALID;
     pn_ctx *ctx = n->ctx;
     if (n->finalized) return pn_set_error(ctx, PN_ERR_STATE, "net already finalized");
-    if (precision != PN_PREC_F32 && precision != PN_PREC_BF16) return pn_set_error(ctx, PN_ERR_INVALID, "bad precision %d", precision);
+    if (precision != PN_PREC_F32 && precision != PN_PREC_BF16 && precision != PN_PREC_BF16X3) return pn_set_error(ctx, PN_ERR_INVALID, "bad precision %d", precision);
     if (max_batch < 1) return pn_set_error(ctx, PN_ERR_INVALID, "max_batch must be >= 1");
     PN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    n->prec = precision; n->max_batch = max_batch; n->in_h = in_h; n->in_w = in_w;
+    n->x3 = precision == PN_PREC_BF16X3;                      // kernels and packing run as bf16; tensors carry three planes
+    n->prec = n->x3 ? PN_PREC_BF16 : precision; n->max_batch = max_batch; n->in_h = in_h; n->in_w = in_w;
     int rc = n->kind == PN_NET_RTPOSE_LIGHT3D ? build_rtpose(n) : build_yolo(n);
     if (rc) return rc;
     for (auto &b : n->bufs) {
@@ -771,7 +790,7 @@ int pn_net_copy_activation(pn_net *n, const char *name, int B, float *dev_out, v
     if (it == n->named.end()) return pn_set_error(ctx, PN_ERR_INVALID, "unknown activation '%s'", name);
     const Buf &b = n->bufs[it->second.first];
     return pn_launch_nhwc_to_nchw(ctx, n->prec, b.p, dev_out, B, b.H, b.W, it->second.second.second, b.C,
-                                  it->second.second.first, (hipStream_t)hip_stream);
+                                  it->second.second.first, n->x3 ? b.plane : 0, (hipStream_t)hip_stream);
 }
 
 int pn_net_read_activation(pn_net *n, const char *name, int B, float *host_out, size_t host_elems, void *hip_stream) {

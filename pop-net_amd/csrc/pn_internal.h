@@ -65,6 +65,11 @@ struct ConvProblem {
     int lds_buf_bytes;     // bytes of one LDS halo image
     int lds_two;           // 1: a second image follows (double-buffered chunks), 0: single image
     unsigned in_zero_off;  // conv3_kernel: byte offset from `in` to >= 16 zero bytes (padding source of the halo DMA)
+    // bf16x3 mode (PN_PREC_BF16X3): a tensor is stored as three bf16 planes [hi | lo | hi] `split` channels apart
+    // (hi = bf16(v), lo = bf16(v - hi)); 0 = plain bf16 / f32 tensor.  The K loop never knows: the input simply has
+    // three times the channels and the packed weights are [W_hi | W_hi | W_lo] (net.hip::prepare_conv).
+    int split;             // plane distance (channels) of the OUTPUT tensor, 0 = not split
+    int res_split;         // plane distance of the residual tensor (hi + lo are added), 0 = not split
 };
 
 // Tile configuration ids (see conv_mfma.hip).
@@ -110,12 +115,12 @@ int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 
 // NHWC T [B,Ho,Wo,64].  w [49][64] f32 (tap-major) for the fp32 VALU kernel, wfrag = the same weights as
 // 8 bf16 MFMA A-fragments (see stem7x7_mfma_kernel) for bf16 mode, bias [64].
 int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const void *wfrag, const float *bias,
-                   void *out, int B, int H, int W, int Ho, int Wo, int out_cs, hipStream_t stream);
+                   void *out, int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream);
 
 // pooling on NHWC T.  mode 0: avg 3x3 s2 p1 (count_include_pad), 1: max 3x3 s2 p1, 2: max 2x2 s2.
 int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, int B, int H, int W,
-                   int C, int in_cs, int out_cs, int out_coff, hipStream_t stream);
+                   int C, int in_cs, int out_cs, int out_coff, int in_split, int out_split, hipStream_t stream);
 
 // NHWC T channel slice -> NCHW f32 (diagnostics / stage-1 outputs).
 int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, int B, int H, int W,
-                           int C, int in_cs, int in_coff, hipStream_t stream);
+                           int C, int in_cs, int in_coff, int split, hipStream_t stream);

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import _lib
 
-_PREC = {"fp32": _lib.PN_PREC_F32, "f32": _lib.PN_PREC_F32, "bf16": _lib.PN_PREC_BF16}
+_PREC = {"fp32": _lib.PN_PREC_F32, "f32": _lib.PN_PREC_F32, "bf16": _lib.PN_PREC_BF16, "bf16x3": _lib.PN_PREC_BF16X3}
 
 
 def default_precision():
@@ -69,7 +69,7 @@ class HipNetModule(nn.Module):
                                    "training-mode BatchNorm / backward are not part of this path")
         prec = _PREC.get(str(self.precision).lower())
         if prec is None:
-            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3', got %r" % (self.precision,))
         key = (device.index, prec, in_h, in_w, self._weights_version())
         if self._net is not None and self._net[1] == key and self._net[2] >= batch:
             return self._net[0]

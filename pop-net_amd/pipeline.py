@@ -24,9 +24,11 @@ from .utils.paf_to_pose import make_parse_cfg
 
 class PoseEngine:
     def __init__(self, precision="bf16", state_dict=None, device=None, max_batch=32, input_size=224,
-                 w_org=480, h_org=640, intrinsics=INTRINSICS, weight_seed=0, private_ctx=False):
+                 w_org=480, h_org=640, intrinsics=INTRINSICS, weight_seed=0, private_ctx=False, calib_gain=1.0):
         """private_ctx: give this engine its own pn_ctx (parse workspace), so that several engines can
-        run concurrently on different HIP streams (bench.py pipelines consecutive batches that way)."""
+        run concurrently on different HIP streams (bench.py pipelines consecutive batches that way).
+        calib_gain: synthetic weights only -- logit gain of the heat head before calibrate_heads (1 = heat values crowd
+        the detection threshold, the worst case for a reduced-precision forward; > 1 = peaks comfortably separated)."""
         if not torch.cuda.is_available():
             raise _lib.PopnetError("PoseEngine needs a GPU: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -34,7 +36,7 @@ class PoseEngine:
         self.model = rtpose_light3d(15, 14, 2, input_dim=1).eval()
         if state_dict is None:
             synth.load_synth_weights(self.model, seed=weight_seed)
-            calibrate_heads(self.model, self.device)
+            calibrate_heads(self.model, self.device, gain=calib_gain)
         else:
             self.model.load_state_dict(state_dict)
         self.model.precision = precision
@@ -347,7 +349,7 @@ def records_to_numpy(frames_dev):
     return frames_dev.cpu().numpy().view(_lib.POSE_FRAME_DTYPE).reshape(-1)
 
 
-def calibrate_heads(model, device=None, frac=0.004, calib_frames=8, seed=99):
+def calibrate_heads(model, device=None, frac=0.004, calib_frames=8, seed=99, gain=1.0):
     """Synthetic-checkpoint calibration (bench / smoke only; never applied to user weights).
 
     With seeded random weights every heat map hovers around sigmoid(0) = 0.5 > THRESH_HEATMAP, i.e.
@@ -366,6 +368,11 @@ def calibrate_heads(model, device=None, frac=0.004, calib_frames=8, seed=99):
                                        float(DEPTH_MEAN), float(DEPTH_STD), _lib.current_stream_ptr(device)), "pn_preprocess")
     prec = model.precision
     model.precision = "fp32"
+    if gain != 1.0:                          # spread the heat logits: fewer cells within a rounding error of the threshold
+        with torch.no_grad():
+            model.model2_2[12].weight[:15] *= float(gain)
+            model.model2_2[12].bias[:15] *= float(gain)
+        model.invalidate()
     (_, heat, _), _ = model(x)
     s = heat[:, :15].double().clamp(1e-12, 1 - 1e-12)
     logit = torch.log(s / (1 - s)).permute(1, 0, 2, 3).reshape(15, -1)

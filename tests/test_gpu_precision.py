@@ -1,0 +1,74 @@
+"""Precision modes of the conv stack against north_star's tolerance (joints within 1e-3 m, person assignment bit-exact).
+
+fp32 (parity mode) is pinned against the reference itself in test_gpu_parity.py.  Here the other modes are measured
+against the fp32 engine, end to end, on 96 frames of the bench workload and on BOTH synthetic weight sets:
+  * threshold-calibrated   heat values crowd the 0.1 detection threshold (calibrate_heads, gain 1): the worst case for
+                           a reduced-precision forward -- any logit error flips a peak;
+  * comfortably separated  the same weights with the heat logits spread 6x before calibration.
+bf16x3 (split-bf16, three MFMAs per product) must MEET the tolerance on both; plain bf16 is the throughput mode: its
+deviation is pinned to the figures DESIGN.md quotes, not claimed to meet 1e-3 m."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import state_dict_from_keys  # noqa: E402
+
+
+def _engines(gpu, prec, gain):
+    from popnet_amd.pipeline import PoseEngine
+    ref = PoseEngine(precision="fp32", device=gpu, max_batch=32, calib_gain=gain)
+    eng = PoseEngine(precision=prec, device=gpu, max_batch=32, calib_gain=gain)
+    for (ka, va), (kb, vb) in zip(ref.model.state_dict().items(), eng.model.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)                       # same calibrated weights in both engines
+    return ref, eng
+
+
+@pytest.mark.parametrize("gain", [1.0, 6.0])
+def test_bf16x3_meets_the_north_star_tolerance_end_to_end(gpu, gain):
+    from popnet_amd.fidelity import compare_engines
+    ref, eng = _engines(gpu, "bf16x3", gain)
+    r = compare_engines(ref, eng, n_frames=96)
+    assert r["frames"] == 96 and r["joints_compared"] > 300, r
+    assert r["same_assignment"] == r["frames"], r                     # person count, peak ids and assignment identical in EVERY frame
+    assert r["d2_px_max"] == 0.0 and r["d3_m_max"] < 1e-3, r           # 2D joints identical, 3D within a millimetre (tolerance: north_star)
+
+
+@pytest.mark.parametrize("gain", [1.0, 6.0])
+def test_bf16_deviation_is_what_the_docs_say(gpu, gain):
+    from popnet_amd.fidelity import compare_engines
+    ref, eng = _engines(gpu, "bf16", gain)
+    r = compare_engines(ref, eng, n_frames=96)
+    # throughput mode: NOT within 1e-3 m; pinned so that a regression (or an improvement) shows up
+    assert r["frames"] == 96
+    assert r["same_person_count"] >= (60 if gain == 1.0 else 80), r
+    assert r["d3_m_median"] < 5e-3 and r["d3_m_p95"] < 5e-2, r
+
+
+def test_bf16x3_forward_maps_vs_reference_golden(gpu, golden):
+    """Same golden vectors as the fp32 forward test (reference nn.Module outputs); tolerance 5e-4 absolute on maps whose
+    range is (-2, 2) / (0, 1): split-bf16 keeps 16 significant bits per operand."""
+    from popnet_amd.network.rtpose_light3d import rtpose_light3d
+    g = golden.forward
+    m = rtpose_light3d(15, 14, 2, input_dim=1).eval()
+    m.load_state_dict(state_dict_from_keys(golden.keys["rtpose_light3d"], seed=0))
+    m.precision = "bf16x3"
+    (paf, heat, z), saved = m(torch.from_numpy(g["x"]).to(gpu))
+    torch.cuda.synchronize()
+    for got, key in ((paf, "rt_paf"), (heat, "rt_heat"), (z, "rt_z")):
+        assert np.abs(got.cpu().numpy() - g[key]).max() < 5e-4, (key, np.abs(got.cpu().numpy() - g[key]).max())
+    assert np.abs(m.stem_features(2).cpu().numpy()[:, ::8, ::2, ::2] - g["rt_feat"]).max() < 5e-4
+    for got, key in ((saved[0], "rt_paf1"), (saved[1], "rt_heat1"), (saved[2], "rt_z1")):
+        assert np.abs(got.cpu().numpy()[:, :, ::4, ::4] - g[key]).max() < 5e-4, key
+
+
+def test_bf16x3_yolo_forward_vs_reference_golden(gpu, golden):
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    g = golden.forward
+    m = YoloPoseNet(15, input_dim=1).eval()
+    m.load_state_dict(state_dict_from_keys(golden.keys["yolo_posenet"], seed=1))
+    m.precision = "bf16x3"
+    out = m(torch.from_numpy(g["x"]).to(gpu))
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - g["yolo_out"]).max() < 5e-3      # activations reach |x| ~ 150 with these weights (fp32 mode: 2e-3)
