@@ -278,10 +278,11 @@ def main():
             nb = engine.preprocess(se.input(0, k % POOL))
             engine.forward(nb)
             ev[k][0].record()
-            engine.parse(nb, se.records(0))                  # post-processing kernels of this step, bracketed on their stream
-            ev[k][1].record()
             if se.wire:
-                engine.pack(se.records(0), se.wires[0])
+                engine.parse(nb, se.records(0), se.wires[0])     # post-processing kernels of this step, bracketed on their stream
+            else:
+                engine.parse(nb, se.records(0))
+            ev[k][1].record()
             ev[k][2].record()
             se.host_records(0).copy_(se.wires[0] if se.wire else se.records(0), non_blocking=True)
             ev[k][3].record()

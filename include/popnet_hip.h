@@ -209,6 +209,11 @@ typedef struct pn_pose_wire {
     float    vals[PN_WIRE_MAX_PERSONS][PN_NUM_JOINTS][6];
 } pn_pose_wire;
 int pn_pack_pose_frames(pn_ctx *ctx, const pn_pose_frame *frames_dev, int B, pn_pose_wire *wire_dev, void *hip_stream);
+/* pn_parse_paf that also writes the compact records (wire_dev: B pn_pose_wire, may be NULL) in the same pass of the
+ * read-out kernel -- identical bytes to pn_parse_paf followed by pn_pack_pose_frames, one launch fewer.               */
+int pn_parse_paf_wire(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev,
+                      int B, int h, int w, const pn_parse_cfg *cfg, pn_pose_frame *frames_dev,
+                      pn_pose_wire *wire_dev, void *hip_stream);
 size_t pn_sizeof_pose_wire(void);
 
 /* ---- Yolo-Pose+ decode ----------------------------------------------------------------------

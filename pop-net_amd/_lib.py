@@ -95,6 +95,7 @@ _SIGNATURES = {
     "pn_net_profile_kernel": (_i, [_vp, _i, C.c_char_p, _sz, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pn_parse_cfg_default": (None, [C.POINTER(ParseCfg)]),
     "pn_parse_paf": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(ParseCfg), _vp, _vp]),
+    "pn_parse_paf_wire": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(ParseCfg), _vp, _vp, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_sizeof_pose_frame": (_sz, []),

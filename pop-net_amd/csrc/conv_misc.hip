@@ -87,10 +87,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int stem_u32x4;
 #define STEM_PITCH 96      // bf16 elements per LDS row: PITCH/2 = 48 = 16 (mod 32) -> the two row groups of a ds_read_b32 phase hit disjoint banks
 
+// X3 (bf16x3 mode): the input patch is kept as hi + lo bf16 parts, the weights as hi + lo fragments (16 instead of 8), and
+// every product is x_hi w_hi + x_lo w_hi + x_hi w_lo -- the stem must not round the depth frame to 8 significant bits.
+template <bool X3>
 __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wfrag,
                                                             const float *__restrict__ bias, __bf16 *__restrict__ out,
                                                             int H, int W, int Ho, int Wo, int out_cs, int split) {
     __shared__ __attribute__((aligned(16))) __bf16 tile[38 * STEM_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 tile_lo[X3 ? 38 * STEM_PITCH : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int b = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
@@ -101,13 +105,18 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
         const int iy = iy0 + r, ix = ix0 + cc;
         float v = 0.f;
         if (r < 37 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[(size_t)iy * W + ix];
-        tile[r * STEM_PITCH + cc] = (__bf16)v;          // row 37 (tap row 7) is zero: its weights are zero, the data must be finite
+        const __bf16 vh = (__bf16)v;
+        tile[r * STEM_PITCH + cc] = vh;                 // row 37 (tap row 7) is zero: its weights are zero, the data must be finite
+        if (X3) tile_lo[r * STEM_PITCH + cc] = (__bf16)(v - (float)vh);
     }
-    stem_bf16x8 aw[4][2];
+    stem_bf16x8 aw[4][2], awl[X3 ? 4 : 1][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) aw[t][s] = *reinterpret_cast<const stem_bf16x8 *>(wfrag + ((t * 2 + s) * 64 + lane) * 8);
+        for (int s = 0; s < 2; ++s) {
+            aw[t][s] = *reinterpret_cast<const stem_bf16x8 *>(wfrag + ((t * 2 + s) * 64 + lane) * 8);
+            if (X3) awl[t][s] = *reinterpret_cast<const stem_bf16x8 *>(wfrag + ((8 + t * 2 + s) * 64 + lane) * 8);
+        }
     float bs[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) bs[i] = bias[16 * q + i];
@@ -125,6 +134,16 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
             stem_bf16x8 bf = *reinterpret_cast<stem_bf16x8 *>(&raw);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t][s], bf, acc[t], 0, 0, 0);
+            if (X3) {
+                const unsigned *srl = reinterpret_cast<const unsigned *>(&tile_lo[(2 * ry + 4 * s + q) * STEM_PITCH + 2 * c]);
+                stem_u32x4 rawl = {srl[0], srl[1], srl[2], srl[3]};
+                stem_bf16x8 bl = *reinterpret_cast<stem_bf16x8 *>(&rawl);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t][s], bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl[t][s], bf, acc[t], 0, 0, 0);
+                }
+            }
         }
         const int oy = oy0 + ry, ox = ox0 + c;
         if (oy < Ho && ox < Wo) {
@@ -152,9 +171,9 @@ int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const 
                    int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream) {
     dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B), block(256);
     if (prec == PN_PREC_BF16)
-        hipLaunchKernelGGL(stem7x7_mfma_kernel, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
-    else if (prec == PN_PREC_BF16X3)     // exact fp32 stem (the MFMA stem rounds the INPUT frame to bf16), split bf16 output
-        hipLaunchKernelGGL(stem7x7_kernel<__bf16>, grid, block, 0, stream, x, w, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
+        hipLaunchKernelGGL(stem7x7_mfma_kernel<false>, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
+    else if (prec == PN_PREC_BF16X3)     // split input and split weights on the matrix cores, split bf16 output
+        hipLaunchKernelGGL(stem7x7_mfma_kernel<true>, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
     else
         hipLaunchKernelGGL(stem7x7_kernel<float>, grid, block, 0, stream, x, w, bias, (float *)out, H, W, Ho, Wo, out_cs, 0);
     PN_HIP_CHECK(ctx, hipGetLastError());

@@ -251,8 +251,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
             cs.R = std::min(ib0.H, rows * cs.wp * (cs.pt / 7));          // rows * Wt <= 112 (224) pixel slots per wave group
             // conv4_kernel (both operands through LDS, 64-cout x 112-pixel wave tiles): the 3x3 layers with Cin >= 128 and
             // >= 64 couts on 4-row strip tiles; a Cin = 64 conv joins only as the sibling of such a layer (one launch per level)
-            if (ks == 3 && cs.wp == 1 && cs.pt == 7 && cs.rpg == 4 && cout >= 64 && (cs.cin_chunks >= 2 || cs.k4_level) &&
-                !getenv("POPNET_NO_CONV4"))
+            if (ks == 3 && cs.wp == 1 && cs.pt == 7 && cs.rpg == 4 && cout >= 64 && cs.k4_level)
                 cs.kern = 4;
         }
     }
@@ -359,6 +358,20 @@ void harmonize_level(pn_net *n, const std::vector<int> &ids) {
             const HostTensor *w = find_t(n, c.w + ".weight");
             if (w && w->shape.size() == 4 && c.ks == 3 && c.stride == 1 && w->shape[0] >= 64 && (n->x3 || std::max<int64_t>(w->shape[1], (int64_t)c.cin_map.size()) > 64)) k4 = true;
         }
+        // conv4's 128-cout x 224-pixel blocks need >= 2 per CU to pay (profiles/README.md r02: level of 448 blocks 37.5 vs
+        // 40.4 us, level of 224 blocks 18.5 vs 12.5 us against conv3_kernel): POPNET_CONV4 = 0 never, 1 whenever eligible,
+        // unset = when the level's 3x3 convs make at least 448 such blocks at max_batch
+        long blocks = 0;
+        for (int id : ids) {
+            const ConvSpec &c = n->convs[id];
+            const HostTensor *w = find_t(n, c.w + ".weight");
+            if (!w || w->shape.size() != 4 || c.ks != 3 || c.stride != 1 || w->shape[0] < 64) continue;
+            const Buf &ib = n->bufs[c.in_buf];
+            const long strips = (long)n->max_batch * ((ib.H + 3) / 4) * ((ib.W + 29) / 30);
+            blocks += ((strips + 1) / 2) * ((w->shape[0] + 127) / 128);
+        }
+        const char *e = getenv("POPNET_CONV4");
+        if (e ? atoi(e) == 0 : blocks < 448) k4 = false;
         if (k4)
             for (int id : ids) n->convs[id].k4_level = 1;
     }
@@ -431,7 +444,7 @@ int add_stem(pn_net *n, int out_buf) {
     PN_HIP_CHECK(ctx, hipMemcpy(st.stem_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     PN_HIP_CHECK(ctx, hipMemcpy(st.stem_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     {   // 8 A-fragments [cout tile t][k-step s][lane][8]: tile row 4q'+r' <-> cout 16q'+4t+r', k = ky*8 + kx+1
-        std::vector<uint16_t> hf(8 * 64 * 8, 0);
+        std::vector<uint16_t> hf(16 * 64 * 8, 0);     // fragments 8..15: the lo halves of the split weights (bf16x3 mode)
         for (int t = 0; t < 4; ++t)
             for (int s2 = 0; s2 < 2; ++s2)
                 for (int lane = 0; lane < 64; ++lane) {
@@ -441,7 +454,12 @@ int add_stem(pn_net *n, int out_buf) {
                     for (int j = 0; j < 8; ++j) {
                         float v = 0.f;
                         if (ky < 7 && j >= 1) v = hw[(ky * 7 + (j - 1)) * 64 + co];
-                        hf[((t * 2 + s2) * 64 + lane) * 8 + j] = f32_to_bf16(v);
+                        const uint16_t hb = f32_to_bf16(v);
+                        hf[((t * 2 + s2) * 64 + lane) * 8 + j] = hb;
+                        uint32_t hu = (uint32_t)hb << 16;
+                        float hi;
+                        memcpy(&hi, &hu, 4);
+                        hf[((8 + t * 2 + s2) * 64 + lane) * 8 + j] = f32_to_bf16(v - hi);
                     }
                 }
         if (int rc = dev_alloc(n, &st.stem_wfrag, hf.size() * 2, false)) return rc;

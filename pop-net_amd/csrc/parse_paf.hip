@@ -41,6 +41,11 @@ __constant__ int c_limb_dst[L_] = {9, 11, 13, 10, 12, 14, 1, 2, 4, 6, 3, 5, 7, 0
 
 struct CubicTab { float c[8][4]; };   // phase p: fractional offset (2p+1)/16
 
+// LDS hand-over between lanes of ONE wave (a wave's LDS instructions execute in order; the waits and the compiler fence
+// make the earlier writes visible to the later reads of other lanes).  Used where the waves of a block run loops of
+// different trip counts, so a block barrier is not available.
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 struct ParseWs {                       // per-frame scratch between the three kernels
     int peak_count[J_];                // uncapped count (overflow detection)
     float peak_x[J_][MAXP], peak_y[J_][MAXP], peak_s[J_][MAXP];
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(256) void peaks_refine_kernel(const float *__restri
     __shared__ int s_wave_cnt[4];
     __shared__ unsigned short s_wlist[4][MAXP];      // per-wave ordered peak lists (cell index)
     __shared__ int s_px[MAXP], s_py[MAXP];
+    __shared__ float s_h[4][5 * 40];                 // per wave: horizontal pass of the patch being refined
     const int joint = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hw = h * w;
@@ -156,19 +162,41 @@ __global__ __launch_bounds__(256) void peaks_refine_kernel(const float *__restri
     if (tid == 0) W.peak_count[joint] = total;
     const int n = min(total, MAXP);
 
-    // one wave per peak: x8 bicubic of the clipped 5x5 patch, first arg-max in row-major order
+    // one wave per peak: x8 bicubic of the clipped 5x5 patch, first arg-max in row-major order.  The up-sampling is
+    // evaluated separably, exactly as cv2 does it (and as bicubic8() does per point): the horizontal pass of each of the
+    // <= 5 source rows once (<= 5 x 40 values, kept in LDS), then the vertical pass per output pixel -- the same float32
+    // operations in the same order as the point-wise form, 4 instead of 16 taps per output pixel.
     for (int p = wave; p < n; p += 4) {
         const int px = s_px[p], py = s_py[p];
         const int x_min = max(0, px - 2), y_min = max(0, py - 2);
         const int x_max = min(w - 1, px + 2), y_max = min(h - 1, py + 2);
         const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;
         const int uw = pw * 8, un = uw * ph * 8;
+        const float inv_uw = 1.0f / (float)uw;
         const float *patch = map + y_min * w + x_min;
+        float *hb = s_h[wave];
+        for (int i = lane; i < ph * uw; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * inv_uw), ux = i - r * uw;
+            int sx0, phx;
+            up8_src(ux, sx0, phx);
+            const float *row = patch + r * w;
+            float hv = row[min(max(sx0, 0), pw - 1)] * tab.c[phx][0];
+            hv = hv + row[min(max(sx0 + 1, 0), pw - 1)] * tab.c[phx][1];
+            hv = hv + row[min(max(sx0 + 2, 0), pw - 1)] * tab.c[phx][2];
+            hv = hv + row[min(max(sx0 + 3, 0), pw - 1)] * tab.c[phx][3];
+            hb[r * 40 + ux] = hv;
+        }
+        WAVE_LDS_SYNC();
         float best = -INFINITY;
         int best_i = 0x7fffffff;
         for (int i = lane; i < un; i += 64) {
-            int uy = i / uw, ux = i - uy * uw;
-            float v = bicubic8(patch, w, ph, pw, uy, ux, tab);
+            const int uy = (int)(((float)i + 0.5f) * inv_uw), ux = i - uy * uw;
+            int sy0, phy;
+            up8_src(uy, sy0, phy);
+            float v = hb[min(max(sy0, 0), ph - 1) * 40 + ux] * tab.c[phy][0];
+            v = v + hb[min(max(sy0 + 1, 0), ph - 1) * 40 + ux] * tab.c[phy][1];
+            v = v + hb[min(max(sy0 + 2, 0), ph - 1) * 40 + ux] * tab.c[phy][2];
+            v = v + hb[min(max(sy0 + 3, 0), ph - 1) * 40 + ux] * tab.c[phy][3];
             if (v > best || best_i == 0x7fffffff) { best = v; best_i = i; }   // i ascending: first max kept
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -177,11 +205,12 @@ __global__ __launch_bounds__(256) void peaks_refine_kernel(const float *__restri
             if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
         }
         if (lane == 0) {
-            int my = best_i / uw, mx = best_i - my * uw;
+            int my = (int)(((float)best_i + 0.5f) * inv_uw), mx = best_i - my * uw;
             W.peak_x[joint][p] = (float)(8 * x_min + mx);
             W.peak_y[joint][p] = (float)(8 * y_min + my);
             W.peak_s[joint][p] = best;
         }
+        WAVE_LDS_SYNC();                                 // the next peak of this wave reuses hb
     }
 }
 
@@ -317,39 +346,46 @@ __global__ __launch_bounds__(256) void limb_match_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------------
 // k3: person assembly + read-out.  grid = B, block = 64 (one wave).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void group_readout_kernel(const float *__restrict__ heat, const float *__restrict__ z,
+__global__ __launch_bounds__(256) void group_readout_kernel(const float *__restrict__ heat, const float *__restrict__ z,
                                                             int h, int w, int heat_c, int z_c, pn_parse_cfg cfg,
-                                                            const ParseWs *__restrict__ ws, pn_pose_frame *__restrict__ frames) {
+                                                            const ParseWs *__restrict__ ws, pn_pose_frame *__restrict__ frames,
+                                                            pn_pose_wire *__restrict__ wire) {
     __shared__ double rows[PN_MAX_PERSONS][J_ + 2];
     __shared__ int s_base[J_ + 1];
-    __shared__ __attribute__((aligned(16))) unsigned s_ws[(sizeof(ParseWs) + 3) / 4];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) unsigned s_ws[(sizeof(ParseWs) + 7) / 8 * 2];
+    __shared__ unsigned long long s_kbal;
+    __shared__ int s_nkeep;
+    // 256 threads: the scratch staging, the joint list and the read-out use all four waves; the serial person assembly
+    // in between runs on wave 0 alone (the other waves wait at the block barrier behind it)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // The assembly below is a serial walk over connections: served from global memory every step was a
     // dependent ~1 us load (measured 25 us per launch).  Stage this frame's 13 KB of scratch in LDS once.
     {
-        const unsigned *src = reinterpret_cast<const unsigned *>(&ws[b]);
-        for (int i = lane; i < (int)(sizeof(ParseWs) / 4); i += 64) s_ws[i] = src[i];
+        static_assert(sizeof(ParseWs) % 8 == 0, "staged in 8-byte pieces");
+        const uint2 *src = reinterpret_cast<const uint2 *>(&ws[b]);
+        for (int i = tid; i < (int)(sizeof(ParseWs) / 8); i += 256) reinterpret_cast<uint2 *>(s_ws)[i] = src[i];
     }
     __syncthreads();
     const ParseWs &W = *reinterpret_cast<const ParseWs *>(s_ws);
     pn_pose_frame &F = frames[b];
     unsigned status = 0;
 
-    if (lane == 0) {
+    if (tid == 0) {
         int acc = 0;
         for (int j = 0; j < J_; ++j) {
             s_base[j] = acc;
-            if (W.peak_count[j] > MAXP) status |= PN_FRAME_OVERFLOW_PEAKS;
             acc += min(W.peak_count[j], MAXP);
         }
         s_base[J_] = acc;
     }
+    for (int j = 0; j < J_; ++j)
+        if (W.peak_count[j] > MAXP) status |= PN_FRAME_OVERFLOW_PEAKS;      // every thread: uniform
     __syncthreads();
     const int npeaks = s_base[J_];
     // joint_list rows (id == row index)
     for (int j = 0; j < J_; ++j) {
         const int n = min(W.peak_count[j], MAXP);
-        for (int k = lane; k < n; k += 64) {
+        for (int k = tid; k < n; k += 256) {
             const int id = s_base[j] + k;
             F.peak_x[id] = W.peak_x[j][k];
             F.peak_y[id] = W.peak_y[j][k];
@@ -358,8 +394,9 @@ __global__ __launch_bounds__(64) void group_readout_kernel(const float *__restri
         }
     }
 
-    // ---- group_limbs_of_same_person (paf_to_pose.py:280-335), wave-uniform control flow ----
+    // ---- group_limbs_of_same_person (paf_to_pose.py:280-335), wave-uniform control flow, wave 0 only ----
     int np = 0;
+    if (wave == 0) {
     for (int limb = 0; limb < L_; ++limb) {
         const int st = c_limb_src[limb], dt = c_limb_dst[limb];
         const int nconn = W.conn_count[limb];
@@ -392,13 +429,13 @@ __global__ __launch_bounds__(64) void group_readout_kernel(const float *__restri
                         rows[p1][J_ + 1] += rows[p2][J_ + 1];
                         rows[p1][J_] += lscore;
                     }
-                    __syncthreads();
+                    WAVE_LDS_SYNC();
                     // person_to_joint_assoc.pop(p2): shift the later rows down by one
                     double tmp[J_ + 2];
                     const bool mv = lane >= p2 && lane < np - 1;
                     if (mv)
                         for (int k = 0; k < J_ + 2; ++k) tmp[k] = rows[lane + 1][k];
-                    __syncthreads();
+                    WAVE_LDS_SYNC();
                     if (mv)
                         for (int k = 0; k < J_ + 2; ++k) rows[lane][k] = tmp[k];
                     --np;
@@ -419,7 +456,7 @@ __global__ __launch_bounds__(64) void group_readout_kernel(const float *__restri
                     status |= PN_FRAME_OVERFLOW_PERSONS;
                 }
             }
-            __syncthreads();
+            WAVE_LDS_SYNC();
         }
     }
 
@@ -429,26 +466,32 @@ __global__ __launch_bounds__(64) void group_readout_kernel(const float *__restri
         const double cnt = rows[lane][J_ + 1], sc = rows[lane][J_];
         keep = !(cnt < 3.0 || sc / cnt < 0.2);
     }
-    const unsigned long long kbal = __ballot(keep);
-    const int nkeep = __popcll(kbal);
+    const unsigned long long kbal0 = __ballot(keep);
     if (keep) {
+        const unsigned long long kbal = kbal0;
         const int o = __popcll(kbal & ((1ull << lane) - 1ull));
         for (int j = 0; j < J_; ++j) F.person_joint[o][j] = (int)rows[lane][j];
         F.person_score[o] = rows[lane][J_];
         F.person_count[o] = (int)rows[lane][J_ + 1];
     }
     if (lane == 0) {
-        F.n_persons = nkeep;
+        F.n_persons = __popcll(kbal0);
         F.n_peaks = npeaks;
-        F.status = __shfl(status, 0) | status;
+        F.status = status;
         F.reserved = 0;
+        s_kbal = kbal0;
+        s_nkeep = __popcll(kbal0);
     }
+    }   // wave 0
+    __syncthreads();
+    const unsigned long long kbal = s_kbal;
+    const int nkeep = s_nkeep;
 
     const int hw = h * w;
     const float *heat_b = heat + (size_t)b * heat_c * hw;
     const float *z_b = z + (size_t)b * z_c * hw;
     const double dsz = (double)cfg.downsample;
-    for (int t = lane; t < nkeep * J_; t += 64) {
+    for (int t = tid; t < nkeep * J_; t += 256) {
         const int o = t / J_, j = t - o * J_;
         // o-th kept row -> source row index
         unsigned long long m = kbal;
@@ -492,17 +535,44 @@ __global__ __launch_bounds__(64) void group_readout_kernel(const float *__restri
             x2 = x / (double)cfg.input_size * (double)cfg.w_org;
             y2 = y / (double)cfg.input_size * (double)cfg.h_org;
         }
+        const double X3 = (x2 - cfg.cx) * depth / cfg.fx, Y3 = (y2 - cfg.cy) * depth / cfg.fy;
         F.joints_2d[o][j][0] = x2;
         F.joints_2d[o][j][1] = y2;
-        F.joints_3d[o][j][0] = (x2 - cfg.cx) * depth / cfg.fx;
-        F.joints_3d[o][j][1] = (y2 - cfg.cy) * depth / cfg.fy;
+        F.joints_3d[o][j][0] = X3;
+        F.joints_3d[o][j][1] = Y3;
         F.joints_3d[o][j][2] = depth;
         F.part_conf[o][j] = conf;
+        if (wire && o < PN_WIRE_MAX_PERSONS) {            // the compact record, in the same pass (what pn_pack_pose_frames derives from F)
+            pn_pose_wire &Wr = wire[b];
+            Wr.person_joint[o][j] = (int16_t)id;
+            Wr.vals[o][j][0] = (float)x2; Wr.vals[o][j][1] = (float)y2;
+            Wr.vals[o][j][2] = (float)X3; Wr.vals[o][j][3] = (float)Y3; Wr.vals[o][j][4] = (float)depth;
+            Wr.vals[o][j][5] = (float)conf;
+        }
+    }
+    if (wire) {
+        pn_pose_wire &Wr = wire[b];
+        if (tid == 0) {
+            Wr.n_persons = nkeep;
+            Wr.status = status | (nkeep > PN_WIRE_MAX_PERSONS ? PN_FRAME_OVERFLOW_PERSONS : 0u);
+        }
+        for (int t = tid; t < PN_WIRE_MAX_PERSONS * J_; t += 256) {      // rows beyond the last person: the same filler pack_pose_kernel writes
+            const int o = t / J_, j = t - o * J_;
+            if (o < nkeep) continue;
+            Wr.person_joint[o][j] = (int16_t)-1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Wr.vals[o][j][k] = 0.f;
+        }
     }
 }
 
 extern "C" int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev, int B, int h,
                             int w, const pn_parse_cfg *cfg, pn_pose_frame *frames_dev, void *hip_stream) {
+    return pn_parse_paf_wire(ctx, heat_dev, paf_dev, z_dev, B, h, w, cfg, frames_dev, nullptr, hip_stream);
+}
+
+extern "C" int pn_parse_paf_wire(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev, int B, int h,
+                                 int w, const pn_parse_cfg *cfg, pn_pose_frame *frames_dev, pn_pose_wire *wire_dev, void *hip_stream) {
     if (!ctx) return PN_ERR_INVALID;
     if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
     if (!heat_dev || !paf_dev || !z_dev || !cfg || !frames_dev || B < 1)
@@ -535,8 +605,8 @@ extern "C" int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf
     hipLaunchKernelGGL(peaks_refine_kernel, dim3(J_, B), dim3(256), 0, s, heat_dev, h, w, J_ + 1, cfg->thresh_heatmap, tab, ws);
     hipLaunchKernelGGL(limb_match_kernel, dim3(L_, B), dim3(256), 0, s, paf_dev, h, w, 2 * L_, cfg->thresh_paf,
                        h * cfg->downsample, tab, ws);
-    hipLaunchKernelGGL(group_readout_kernel, dim3(B), dim3(64), 0, s, heat_dev, z_dev, h, w, J_ + 1, L_ + 1, *cfg,
-                       (const ParseWs *)ws, frames_dev);
+    hipLaunchKernelGGL(group_readout_kernel, dim3(B), dim3(256), 0, s, heat_dev, z_dev, h, w, J_ + 1, L_ + 1, *cfg,
+                       (const ParseWs *)ws, frames_dev, wire_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }

@@ -113,10 +113,11 @@ def run_sweep(engine, frames, batch_size=32, rank=0, world=1, drop_last=False, g
     return local.cpu().numpy().view(dtype).reshape(-1)
 
 
-def run_sweep_streaming(se, frames, batch_size=32, rank=0, world=1, drop_last=False, group=None):
+def run_sweep_streaming(se, frames, batch_size=32, rank=0, world=1, drop_last=False, group=None, gather=True):
     """Same result as run_sweep, through a pipeline.StreamingEngine: batch k+1 is read from disk, pinned and copied to
     the device (on its slot's stream) while batches k, k-1 are still being computed; a slot's records are collected right
-    before the slot is reused."""
+    before the slot is reused.  gather=False returns this rank's shard only (device uint8 [n_local, item], frames
+    rank, rank + world, ...) without touching torch.distributed."""
     import torch
     from .pipeline import gather_records, shard_indices
     n = len(frames)
@@ -160,6 +161,8 @@ def run_sweep_streaming(se, frames, batch_size=32, rank=0, world=1, drop_last=Fa
         collect(slot)
     se.join()
     torch.cuda.synchronize(se.device)
+    if not gather:
+        return local
     if world > 1:
         local = gather_records(local, n, rank, world, group)
     dtype = _lib.POSE_FRAME_DTYPE if item == _lib.POSE_FRAME_DTYPE.itemsize else _lib.YOLO_FRAME_DTYPE

@@ -91,18 +91,20 @@ class PoseEngine:
                                                 C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.z.data_ptr()),
                                                 _lib.current_stream_ptr(self.device)), "pn_rtpose_forward")
 
-    def parse(self, B, frames=None):
+    def parse(self, B, frames=None, wire=None):
+        """wire: optional device uint8 tensor [>= B, sizeof(pn_pose_wire)] that receives the compact records in the same launch."""
         frames = self.frames if frames is None else frames
         h = self.S // 8
-        self.ctx.check(self.L.pn_parse_paf(self.ctx.handle, C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.paf.data_ptr()),
-                                           C.c_void_p(self.z.data_ptr()), B, h, h, C.byref(self.cfg),
-                                           C.c_void_p(frames.data_ptr()), _lib.current_stream_ptr(self.device)), "pn_parse_paf")
+        self.ctx.check(self.L.pn_parse_paf_wire(self.ctx.handle, C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.paf.data_ptr()),
+                                                C.c_void_p(self.z.data_ptr()), B, h, h, C.byref(self.cfg), C.c_void_p(frames.data_ptr()),
+                                                C.c_void_p(wire.data_ptr() if wire is not None else None),
+                                                _lib.current_stream_ptr(self.device)), "pn_parse_paf_wire")
 
-    def predict(self, depth, frames=None):
+    def predict(self, depth, frames=None, wire=None):
         """depth [B,H,W] CUDA f16/f32 -> device uint8 tensor [B, sizeof(pn_pose_frame)] (no sync)."""
         B = self.preprocess(depth)
         self.forward(B)
-        self.parse(B, frames)
+        self.parse(B, frames, wire)
         return (self.frames if frames is None else frames)[:B]
 
     def predict_host(self, depth):
@@ -275,11 +277,11 @@ class StreamingEngine:
 
     def _body(self, s, j=0):
         e = self.engines[s]
-        e.predict(self.inputs[s][j], self.recs[s])
         if self.wire:
-            e.pack(self.recs[s], self.wires[s])
+            e.predict(self.inputs[s][j], self.recs[s], self.wires[s])      # full and compact records from the same read-out launch
             self.host[s].copy_(self.wires[s], non_blocking=True)
         else:
+            e.predict(self.inputs[s][j], self.recs[s])
             self.host[s].copy_(self.recs[s], non_blocking=True)
 
     def capture(self):
@@ -401,7 +403,12 @@ def gather_records(local_frames, n_frames, rank, world, group=None):
     pad[:local_frames.shape[0]] = local_frames
     out = torch.empty((world * per, item), dtype=torch.uint8, device=local_frames.device)
     dist.all_gather_into_tensor(out, pad, group=group)
-    out = out.view(world, per, item)
-    # de-interleave: global frame i = (rank i % world, slot i // world)
-    idx = torch.arange(n_frames, device=out.device)
-    return out[idx % world, idx // world]
+    return deinterleave(out.view(world, per, item), n_frames)
+
+
+def deinterleave(per_rank, n_frames):
+    """[world, per, item] records as the all-gather delivers them (rank-major) -> [n_frames, item] in global frame order:
+    frame i was processed by rank i % world as its (i // world)-th frame (shard_indices)."""
+    world = per_rank.shape[0]
+    idx = torch.arange(n_frames, device=per_rank.device)
+    return per_rank[idx % world, idx // world]

@@ -144,3 +144,30 @@ def synth_depth(B, H=640, W=480, seed=1234, dtype=np.float16):
     d = np.clip(up + rng.normal(0, 0.05, (B, H, W)), 0, 6)
     d[rng.random((B, H, W)) < 0.04] = 0
     return d.astype(dtype)
+
+
+class SynthSweep:
+    """A synthetic MP-3DHP split of n DISTINCT frames without n files: frame i is pool frame i % len(pool) rolled by
+    i // len(pool) rows, so every frame has its own content and a sweep can be checked for order and coverage.  Duck-types
+    dataset.MP3DHPFrames for run_sweep / run_sweep_streaming (BASELINE configs[2]: the 4 484-frame test_mpreal sweep)."""
+
+    def __init__(self, n_frames, pool=64, H=640, W=480, seed=4484):
+        self.n = int(n_frames)
+        self.pool = synth_depth(pool, H, W, seed=seed)
+        self.ids = ["synth_%05d.npy" % i for i in range(self.n)]
+        from .config import INTRINSICS
+        self.intrinsics = dict(INTRINSICS)
+
+    def __len__(self):
+        return self.n
+
+    def load(self, index):
+        return np.roll(self.pool[index % len(self.pool)], index // len(self.pool), axis=0)
+
+    def batches(self, indices, batch_size, drop_last=False):
+        indices = list(indices)
+        for s in range(0, len(indices), batch_size):
+            chunk = indices[s:s + batch_size]
+            if drop_last and len(chunk) < batch_size:
+                return
+            yield chunk, np.stack([self.load(i) for i in chunk])

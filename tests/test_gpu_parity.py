@@ -155,21 +155,27 @@ def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, mo
     do_yolo = H % 16 == 0 and W % 16 == 0
     got = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
     got_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.setenv("POPNET_CONV4", "1")              # conv4_kernel on every eligible level (the default picks it by block count)
+    got4 = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
+    got4_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.delenv("POPNET_CONV4")
     monkeypatch.setenv("POPNET_NO_CONV3", "1")          # read when the net is compiled
     ref = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
     ref_y = yolo()(x).clone() if do_yolo else None
     monkeypatch.delenv("POPNET_NO_CONV3")
     f32 = [t.clone() for t in _rtpose(golden, "fp32")(x)[0]]
     torch.cuda.synchronize()
-    for a, b, c, name in zip(got, ref, f32, ("paf", "heat", "z")):
+    for a, a4, b, c, name in zip(got, got4, ref, f32, ("paf", "heat", "z")):
         assert torch.isfinite(a).all() and torch.equal(a, b), name
+        assert torch.equal(a4, b), ("conv4", name)
         d = (a - c).abs()
         assert float(d.max()) < 0.15 and float(d.mean()) < 0.02, (name, float(d.max()), float(d.mean()))
     if do_yolo:
         assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y)
+        assert torch.equal(got4_y, ref_y)
 
 
-@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1"])
+@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0"])
 def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, monkeypatch):
     """The experiment switches of profiles/README.md (224-pixel wave tiles, double-buffered halo images, 8-row tiles on
     14-column maps) select other conv3_kernel instantiations of the same arithmetic: same maps, bit for bit, as the
@@ -625,6 +631,11 @@ def test_wire_records_match_full_records(gpu):
         assert np.array_equal(w["vals"][:n, :, 0:2], f["joints_2d"][:n].astype(np.float32))
         assert np.array_equal(w["vals"][:n, :, 2:5], f["joints_3d"][:n].astype(np.float32))
         assert np.array_equal(w["vals"][:n, :, 5], f["part_conf"][:n].astype(np.float32))
+    # pn_parse_paf_wire writes the compact records in the read-out launch itself: the same bytes as parse + pack
+    fused = torch.zeros((8, _lib.POSE_WIRE_DTYPE.itemsize), device=gpu, dtype=torch.uint8)
+    frames2 = eng.predict(depth, torch.empty_like(frames), fused)
+    torch.cuda.synchronize()
+    assert torch.equal(frames2, frames) and torch.equal(fused, eng.pack(frames))
     a, b = wire_to_lists(wire), pose_records_to_lists(full)
     assert a["human_pred_set_visibility"] == b["human_pred_set_visibility"]
     assert np.allclose(np.array(a["human_pred_set_3d"][0]), np.array(b["human_pred_set_3d"][0]), atol=1e-5) or len(a["human_pred_set_3d"][0]) == 0
