@@ -1,0 +1,262 @@
+// Fused ResNet BasicBlock(64) on the CDNA4 matrix cores (bf16 storage, fp32 accumulate):
+//     y = relu( conv3x3(relu(conv3x3(x, W1) + b1), W2) + b2 + x )            64 -> 64 -> 64 channels, stride 1
+// replaces the two launches per block of tpm/lib/network/rtpose_light3d.py:48-72 (BasicBlock.forward) for model0.layer1
+// (tpm/lib/network/rtpose_light3d.py:145-152) and resnet.BasicBlock (tpm/lib/network/resnet.py:27-56) for YoloPoseNet's
+// layer1.  BatchNorm is folded into W / b on the host (net.hip).
+//
+// Why: at 112x112 these layers are not arithmetic: unfused, a BasicBlock moves 297 MB per 32 frames (conv1 reads x with
+// its halo and writes the 51 MB intermediate, conv2 reads it back with halo, reads x again as the residual and writes
+// y) in memory-bound prologue / epilogue phases that every resident block runs in lockstep (45 us per conv for 12 us of
+// MFMA work, profiles/README.md r01 v21).  Here the intermediate never leaves the CU and x is read once:
+//   * one PERSISTENT workgroup per CU walks its share of the 8-row x <=28-column output tiles;
+//   * per tile the 12 x 32-pixel input halo (48 KB, half-major [half][row][32 px][64 B]) sits in LDS, conv1 is evaluated on
+//     the 10 x 30 intermediate halo (1.34x recompute) straight into a second LDS image (40 KB, zero outside the map =
+//     conv2's padding), conv2 reads that image, the residual comes from the CENTRE of the input image (no second read
+//     of x), and y leaves with 16-B stores;
+//   * the input image is double-buffered: the next tile's image is fetched during this tile's conv1, the stores of
+//     this tile drain under the next tile's conv1 -- no lockstep memory phases;
+//   * 8 waves with FIXED ROLES: waves 0-3 compute (each 64 couts x 5 / 4 pixel tiles: 20 / 16 MFMAs per k-step, B
+//     fragments from the images, A fragments from a 3-slot LDS ring), waves 4-7 only issue LDS-DMA (weights: one 4 KB
+//     k-step per phase, W1 | W2 as one periodic 36-step stream; input image pieces) and count their own vmcnt -- a
+//     compute wave's instruction stream is MFMA + ds_read only (conv4_kernel's ablations: DMA issue and its waits cost a
+//     lone wave 80 of 717 cycles per k-step);
+//   * one barrier per k-step, 148 KB of LDS, one workgroup per CU.
+// Weight pack (net.hip): [36 k-steps = (conv, half, tap)][4 cout tiles][64 lanes][8 bf16], rows permuted with
+// pn_conv_row_channel(tile, row, 4) so that a lane's 16 accumulators are 16 consecutive channels.
+#pragma once
+#include "conv3_kernel.h"
+
+
+#define BB_INHALF (12 * 32 * 64)
+#define BB_IN (2 * BB_INHALF)                 // 48 KB
+#define BB_MIDHALF (10 * 32 * 64)
+#define BB_MID (2 * BB_MIDHALF)               // 40 KB
+#define BB_ASLOT 4096
+#define BB_OFF_MID (2 * BB_IN)
+#define BB_OFF_A (BB_OFF_MID + BB_MID)
+#define BB_LDS (BB_OFF_A + 3 * BB_ASLOT)      // 151552 B
+
+__global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
+    typedef __bf16 T;
+    constexpr int CT = 4, PT1 = 5, PT2 = 4, KK = 9, BQ = 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int W = P.W, H = P.H;
+
+    auto tile_geom = [&](int t, int &b, int &oy0, int &ox0, int &R, int &Wc) {
+        b = t / P.tiles_per_img;
+        const int rem = t - b * P.tiles_per_img;
+        const int ty = rem / P.tiles_x, tx = rem - ty * P.tiles_x;
+        oy0 = ty * 8; ox0 = tx * P.Wt;
+        R = min(8, H - oy0); Wc = min(P.Wt, W - ox0);
+    };
+
+    if (wave >= 4) {
+        // ================= loader waves: LDS-DMA only =================
+        const int lw = wave - 4;
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const char *wsrc0 = (const char *)P.wpack + lw * 1024;
+        auto dma_a = [&](int kstep, int slot) {                // k-step of the periodic 36-step stream -> ring slot
+            pn_glds16_s<0>(wsrc0 + (size_t)kstep * BB_ASLOT, lane16, (unsigned)(BB_OFF_A + slot * BB_ASLOT) + (unsigned)__builtin_amdgcn_readfirstlane(lw * 1024));
+        };
+        auto dma_in = [&](int t, int buf, int j) {             // piece n = lw * 12 + j of tile t's input image -> IN[buf]
+            int b, oy0, ox0, R, Wc;
+            tile_geom(t, b, oy0, ox0, R, Wc);
+            const int n = lw * 12 + j;
+            const int half = n / 24, row = (n % 24) >> 1, g = n & 1;
+            const int px = g * 16 + (lane >> 2);
+            const int iy = oy0 - 2 + row, ix = ox0 - 2 + px;
+            const size_t frame_b = ((size_t)b * H * W * P.in_cs + P.in_coff) * 2;
+            const bool inb = px < Wc + 4 && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
+            const unsigned off = inb ? (unsigned)((iy * W + ix) * P.in_cs * 2 + half * 64 + (lane & 3) * 16) : P.in_zero_off - (unsigned)frame_b;
+            pn_glds16_s<0>((const char *)P.in + frame_b, off, (unsigned)__builtin_amdgcn_readfirstlane(buf * BB_IN + half * BB_INHALF + (row * 32 + g * 16) * 64));
+        };
+        int t = blockIdx.x;
+        if (t >= P.ntiles) return;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) dma_in(t, 0, j);
+        dma_a(0, 0); dma_a(1, 1); dma_a(2, 2);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");              // the compute waves have read k-step 0's fragments: ring slot 0 may be refilled
+        int cur = 0;
+        for (; t < P.ntiles; t += gridDim.x) {
+            const int tn = t + (int)gridDim.x < P.ntiles ? t + (int)gridDim.x : t;      // past the last tile: a harmless refetch into the idle image
+#pragma clang loop unroll(full)
+            for (int ph = 0; ph < 36; ++ph) {
+                if (ph < 12) dma_in(tn, cur ^ 1, ph);
+                dma_a((ph + 3) % 36, ph % 3);
+                if (ph < 12) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+                if (ph == 17) asm volatile("s_barrier" ::: "memory");          // the compute waves publish the intermediate image
+            }
+            asm volatile("s_barrier" ::: "memory");                             // end of tile: residual reads of IN[cur] are done
+            cur ^= 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ================= compute waves =================
+    int t = blockIdx.x;
+    if (t >= P.ntiles) return;
+    const float *bias1 = P.bias1, *bias2 = P.bias2;
+    float b1[16], b2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { b1[i] = bias1[16 * q + i]; b2[i] = bias2[16 * q + i]; }
+    const int aaddr = BB_OFF_A + lane * 16;
+    bf16x8 aq[2][CT], bq[BQ];
+    asm volatile("s_barrier" ::: "memory");             // prologue: first image + weight k-steps 0..2 landed
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) aq[0][ct] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ct * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int cur = 0;
+    for (; t < P.ntiles; t += gridDim.x) {
+        int b, oy0, ox0, R, Wc;
+        tile_geom(t, b, oy0, ox0, R, Wc);
+        const int MC = Wc + 2, nmid = (R + 2) * MC, nout = R * Wc;
+        const float inv_mc = 1.0f / (float)MC, inv_wc = 1.0f / (float)Wc;
+        const int inb = cur * BB_IN;
+        // per-lane image addresses (tap and half are immediates)
+        int ba1[PT1], ba2[PT2];
+#pragma unroll
+        for (int pt = 0; pt < PT1; ++pt) {
+            const int s0 = (wave * PT1 + pt) * 16 + c, s = s0 < nmid ? s0 : 0;
+            const int r = (int)(((float)s + 0.5f) * inv_mc), x = s - r * MC;
+            ba1[pt] = inb + q * 16 + (r * 32 + x) * 64;
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT2; ++pt) {
+            const int s0 = (wave * PT2 + pt) * 16 + c, s = s0 < nout ? s0 : 0;
+            const int r = (int)(((float)s + 0.5f) * inv_wc), x = s - r * Wc;
+            ba2[pt] = BB_OFF_MID + q * 16 + (r * 32 + x) * 64;
+        }
+        f32x4 acc[CT][PT1];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT1; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (aq[0] holds k-step 0's weight fragments: read in the prologue / prefetched by the previous tile's last phase)
+        // ---------------- conv1: 18 k-steps on the input image ----------------
+#define BB_TAPOFF(tap) ((((tap) / 3) * 32 + ((tap) % 3)) * 64)
+#define BB_OFF1(j) ((((j) / PT1) / KK) * BB_INHALF + BB_TAPOFF(((j) / PT1) % KK))
+#pragma unroll
+        for (int j = 0; j < BQ - 1; ++j) bq[j] = *reinterpret_cast<const bf16x8 *>(smem + ba1[j % PT1] + BB_OFF1(j));
+#pragma clang loop unroll(full)
+        for (int ph = 0; ph < 18; ++ph) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(full)
+            for (int pt = 0; pt < PT1; ++pt) {
+                const int j = ph * PT1 + pt, jr = j + BQ - 1;
+                if (pt < CT)
+                    aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % 3) * BB_ASLOT + pt * 1024);
+                if (jr < 18 * PT1) bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + ba1[jr % PT1] + BB_OFF1(jr));
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ph & 1][ct], bq[j % BQ], acc[ct][pt], 0, 0, 0);
+                if (pt < CT && jr < 18 * PT1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (pt < CT || jr < 18 * PT1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // ---------------- intermediate: bias + ReLU -> bf16 -> LDS image (zero outside the map) ----------------
+#pragma clang loop unroll(full)
+        for (int pt = 0; pt < PT1; ++pt) {
+            const int s = (wave * PT1 + pt) * 16 + c;
+            const int r = (int)(((float)s + 0.5f) * inv_mc), x = s - r * MC;
+            const int my = oy0 - 1 + r, mx = ox0 - 1 + x;
+            const bool inside = (unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W;
+            T ov[16];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[ct][pt][i] + b1[4 * ct + i];
+                    v = v > 0.f ? v : 0.f;
+                    ov[4 * ct + i] = (T)(inside ? v : 0.f);
+                }
+            if (s < nmid) {
+                u32x4 *dst = reinterpret_cast<u32x4 *>(smem + BB_OFF_MID + (q >> 1) * BB_MIDHALF + (r * 32 + x) * 64 + (q & 1) * 32);
+                dst[0] = reinterpret_cast<u32x4 *>(ov)[0];
+                dst[1] = reinterpret_cast<u32x4 *>(ov)[1];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---------------- conv2: 18 k-steps on the intermediate image ----------------
+#define BB_OFF2(j) ((((j) / PT2) / KK) * BB_MIDHALF + BB_TAPOFF(((j) / PT2) % KK))
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < BQ - 1; ++j) bq[j] = *reinterpret_cast<const bf16x8 *>(smem + ba2[j % PT2] + BB_OFF2(j));
+#pragma clang loop unroll(full)
+        for (int p2 = 0; p2 < 18; ++p2) {
+            const int ph = 18 + p2;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(full)
+            for (int pt = 0; pt < PT2; ++pt) {
+                const int j = p2 * PT2 + pt, jr = j + BQ - 1;
+                aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % 3) * BB_ASLOT + pt * 1024);
+                if (jr < 18 * PT2) bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + ba2[jr % PT2] + BB_OFF2(jr));
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ph & 1][ct], bq[j % BQ], acc[ct][pt], 0, 0, 0);
+                if (jr < 18 * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // ---------------- output: bias + residual (centre of the input image) + ReLU, 2 x 16-B stores per pixel ----------------
+        {
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (char *)P.out + ((size_t)b * H * W * P.out_cs + P.out_coff) * 2, 0, (int)((size_t)H * W * P.out_cs * 2), 0x00020000);
+#pragma clang loop unroll(full)
+            for (int pt = 0; pt < PT2; ++pt) {
+                const int s = (wave * PT2 + pt) * 16 + c;
+                const int r = (int)(((float)s + 0.5f) * inv_wc), x = s - r * Wc;
+                const bool valid = s < nout;
+                const u32x4 *rp = reinterpret_cast<const u32x4 *>(smem + inb + (q >> 1) * BB_INHALF + (((valid ? r : 0) + 2) * 32 + (valid ? x : 0) + 2) * 64 + (q & 1) * 32);
+                T rv[16];
+                reinterpret_cast<u32x4 *>(rv)[0] = rp[0];
+                reinterpret_cast<u32x4 *>(rv)[1] = rp[1];
+                T ov[16];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[ct][pt][i] + b2[4 * ct + i];
+                        v += (float)rv[4 * ct + i];
+                        ov[4 * ct + i] = (T)(v > 0.f ? v : 0.f);
+                    }
+                // out-of-range offset for the unused slots: the store is issued unconditionally and dropped by the hardware
+                const unsigned voff = valid ? (unsigned)(((oy0 + r) * W + ox0 + x) * P.out_cs * 2 + 32 * q) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4 *>(ov)[0], orsrc, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4 *>(ov)[1], orsrc, voff + 16u, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the loader may now refill this image's buffer
+        cur ^= 1;
+    }
+#undef BB_OFF1
+#undef BB_OFF2
+#undef BB_TAPOFF
+}
+
+static int bb64_launch(pn_ctx *ctx, const BBProblem &P, int num_cus, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bb64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS));
+        configured = true;
+    }
+    const int grid = P.ntiles < num_cus ? P.ntiles : num_cus;
+    hipLaunchKernelGGL(bb64_kernel, dim3(grid), dim3(512), BB_LDS, stream, P);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}

@@ -43,6 +43,14 @@ __device__ __forceinline__ void pn_glds16(gcptr src, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 
+// LDS-DMA, scalar base + 32-bit lane offset: no 64-bit address registers, the per-step pointer bump is scalar.
+template <int IMM>
+__device__ __forceinline__ void pn_glds16_s(const void *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM) : "memory");
+}
+
 // PT = pixel tiles of 16 per wave: 7 (112 pixels = 4 rows of a 28-column strip, 56 accumulator VGPRs, 4 waves / SIMD) or
 // 14 (224 pixels = 8 rows, 112 accumulator VGPRs, 2 waves / SIMD: half the weight bytes per MFMA, for Cin = 64 layers
 // on large maps, whose 224-pixel tiles otherwise stream their whole weight slice twice).

@@ -26,14 +26,6 @@
 #pragma once
 #include "conv3_kernel.h"
 
-// LDS-DMA, scalar base + 32-bit lane offset: no 64-bit address registers, the per-step pointer bump is scalar.
-template <int IMM>
-__device__ __forceinline__ void pn_glds16_s(const void *sbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM) : "memory");
-}
-
 #define PN4_ASLOT 8192                  // one k-step of weight fragments: 8 cout tiles x 1 KB
 #define PN4_ARING (3 * PN4_ASLOT)
 #define PN4_BSTRIP (6 * 32 * 64)        // one 32-channel half image of one strip: 6 halo rows x 32 px x 64 B

@@ -57,7 +57,11 @@ struct ConvSpec {
 };
 
 struct Step {
-    enum Type { STEM, POOL, CONV } type;
+    enum Type { STEM, POOL, CONV, BBLOCK } type;
+    // BBLOCK: fused BasicBlock(64) = convs[bb_a] (3x3 + ReLU) -> convs[bb_b] (3x3 + residual + ReLU), bb64_kernel.h
+    int bb_a = -1, bb_b = -1, bb_wt = 0;
+    void *bb_wpack = nullptr;
+    float *bb_bias1 = nullptr, *bb_bias2 = nullptr;
     // STEM
     int out_buf = -1;
     float *stem_w = nullptr, *stem_b = nullptr;
@@ -470,6 +474,85 @@ int add_stem(pn_net *n, int out_buf) {
     return PN_OK;
 }
 
+
+// Folded (BatchNorm -> weight scale / bias shift) parameters of one conv, as prepare_conv computes them.
+int fold_bn(pn_net *n, const ConvSpec &cs, int cout, std::vector<double> &scale, std::vector<double> &shift) {
+    scale.assign(cout, 1.0); shift.assign(cout, 0.0);
+    const HostTensor *bias = find_t(n, cs.w + ".bias");
+    for (int o = 0; o < cout; ++o) shift[o] = bias ? bias->data[o] : 0.0;
+    if (!cs.bn.empty()) {
+        const HostTensor *g = find_t(n, cs.bn + ".weight"), *be = find_t(n, cs.bn + ".bias");
+        const HostTensor *mu = find_t(n, cs.bn + ".running_mean"), *var = find_t(n, cs.bn + ".running_var");
+        if (!g || !be || !mu || !var) return pn_set_error(n->ctx, PN_ERR_INVALID, "missing BatchNorm tensors %s.*", cs.bn.c_str());
+        for (int o = 0; o < cout; ++o) {
+            const double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+            scale[o] = s;
+            shift[o] = (shift[o] - (double)mu->data[o]) * s + (double)be->data[o];
+        }
+    }
+    return PN_OK;
+}
+
+// BasicBlock(64) pairs (conv a: 3x3 64->64 + ReLU into a scratch buffer; conv b: 3x3 64->64 on it + residual = a's input +
+// ReLU) become ONE level {-2, a, b} run by bb64_kernel.  bf16 only (not bf16x3: three planes do not fit the LDS images).
+void fuse_basic_blocks(pn_net *n, std::vector<std::vector<int>> &levels) {
+    if (n->prec != PN_PREC_BF16 || n->x3 || getenv("POPNET_NO_BBLOCK") || getenv("POPNET_NO_CONV3")) return;
+    for (size_t i = 0; i + 1 < levels.size(); ++i) {
+        if (levels[i].size() != 1 || levels[i + 1].size() != 1 || levels[i][0] < 0 || levels[i + 1][0] < 0) continue;
+        const ConvSpec &a = n->convs[levels[i][0]], &b = n->convs[levels[i + 1][0]];
+        const HostTensor *wa = find_t(n, a.w + ".weight"), *wb = find_t(n, b.w + ".weight");
+        if (!wa || !wb || wa->shape.size() != 4 || wb->shape.size() != 4) continue;
+        auto is64 = [](const HostTensor *w) { return w->shape[0] == 64 && w->shape[1] == 64 && w->shape[2] == 3 && w->shape[3] == 3; };
+        if (!is64(wa) || !is64(wb) || a.stride != 1 || b.stride != 1 || a.kern != 3 || b.kern != 3) continue;
+        if (a.act != PN_ACT_RELU || b.act != PN_ACT_RELU || a.res_buf >= 0 || b.res_buf != a.in_buf || b.in_buf != a.out_buf) continue;
+        if (a.in_coff || a.out_coff || b.in_coff || b.res_coff || a.nchw_slot >= 0 || b.nchw_slot >= 0 || b.out_buf < 0 || !a.cin_map.empty() || !b.cin_map.empty()) continue;
+        const Buf &ib = n->bufs[a.in_buf];
+        if (ib.W < 8 || ib.H < 8) continue;
+        const int ids[2] = {levels[i][0], levels[i + 1][0]};
+        levels[i] = {-2, ids[0], ids[1]};
+        levels.erase(levels.begin() + i + 1);
+    }
+}
+
+int add_bblock(pn_net *n, int ia, int ib) {
+    pn_ctx *ctx = n->ctx;
+    Step st;
+    st.type = Step::BBLOCK;
+    st.bb_a = ia; st.bb_b = ib;
+    const Buf &inb = n->bufs[n->convs[ia].in_buf];
+    const int segs = (inb.W + 27) / 28;
+    st.bb_wt = (inb.W + segs - 1) / segs;                    // <= 28 columns: the 32-pixel halo row holds Wt + 4
+    std::vector<uint16_t> pk((size_t)36 * 4 * 64 * 8, 0);
+    std::vector<float> hb[2];
+    for (int cv = 0; cv < 2; ++cv) {
+        const ConvSpec &cs = n->convs[cv ? ib : ia];
+        const HostTensor *w = find_t(n, cs.w + ".weight");
+        std::vector<double> scale, shift;
+        if (int rc = fold_bn(n, cs, 64, scale, shift)) return rc;
+        hb[cv].resize(64);
+        for (int o = 0; o < 64; ++o) hb[cv][o] = (float)shift[o];
+        for (int hh = 0; hh < 2; ++hh)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int t = 0; t < 4; ++t)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = pn_conv_row_channel(t, lane & 15, 4), q = lane >> 4;
+                        const size_t base = ((((size_t)cv * 18 + hh * 9 + tap) * 4 + t) * 64 + lane) * 8;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = hh * 32 + 8 * q + j;
+                            pk[base + j] = f32_to_bf16((float)((double)w->data[((size_t)co * 64 + ci) * 9 + tap] * scale[co]));
+                        }
+                    }
+    }
+    if (int rc = dev_alloc(n, &st.bb_wpack, pk.size() * 2, false)) return rc;
+    PN_HIP_CHECK(ctx, hipMemcpy(st.bb_wpack, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    if (int rc = dev_alloc(n, (void **)&st.bb_bias1, 64 * 4, false)) return rc;
+    if (int rc = dev_alloc(n, (void **)&st.bb_bias2, 64 * 4, false)) return rc;
+    PN_HIP_CHECK(ctx, hipMemcpy(st.bb_bias1, hb[0].data(), 64 * 4, hipMemcpyHostToDevice));
+    PN_HIP_CHECK(ctx, hipMemcpy(st.bb_bias2, hb[1].data(), 64 * 4, hipMemcpyHostToDevice));
+    n->steps.push_back(st);
+    return PN_OK;
+}
+
 // ---- graph builders -------------------------------------------------------------------------
 int build_rtpose(pn_net *n) {
     const int H = n->in_h, W = n->in_w;
@@ -542,12 +625,14 @@ int build_rtpose(pn_net *n) {
     }
 
     for (auto &lv : levels)
-        if (lv[0] != -1) harmonize_level(n, lv);
+        if (lv[0] >= 0) harmonize_level(n, lv);
     for (auto &cs : n->convs)
         if (int rc = prepare_conv(n, cs)) return rc;
     for (auto &cs : n->convs) n->flops_per_frame += cs.flops;
+    fuse_basic_blocks(n, levels);
     for (auto &lv : levels) {
         if (lv[0] == -1) add_pool(n, lv[1], lv[2], lv[3], lv[4], lv[5]);
+        else if (lv[0] == -2) { if (int rc = add_bblock(n, lv[1], lv[2])) return rc; }
         else add_conv_level(n, lv);
     }
     return PN_OK;
@@ -600,8 +685,10 @@ int build_yolo(pn_net *n) {
     for (auto &cs : n->convs)
         if (int rc = prepare_conv(n, cs)) return rc;
     for (auto &cs : n->convs) n->flops_per_frame += cs.flops;
+    fuse_basic_blocks(n, levels);
     for (auto &lv : levels) {
         if (lv[0] == -1) add_pool(n, lv[1], lv[2], lv[3], lv[4], lv[5]);
+        else if (lv[0] == -2) { if (int rc = add_bblock(n, lv[1], lv[2])) return rc; }
         else add_conv_level(n, lv);
     }
     return PN_OK;
@@ -702,6 +789,11 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
                 else snprintf(lb, sizeof lb, "conv_mfma_kernel<%d, %d, %d, %d, %d>", cl.prec, cl.ks, cl.stride, cl.pitch, cl.cfg);
                 pr->label = lb;
             }
+            if (st.type == Step::BBLOCK) {       // counted with the convolutions: both convs' algorithmic FLOPs
+                pr->kind = (int)Step::CONV;
+                pr->flops = (n->convs[st.bb_a].flops + n->convs[st.bb_b].flops) * B;
+                pr->label = "bb64_kernel";
+            }
             PN_HIP_CHECK(ctx, hipEventRecord(pr->a, stream));
         }
         if (st.type == Step::STEM) {
@@ -710,6 +802,19 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         } else if (st.type == Step::POOL) {
             const Buf &ib = n->bufs[st.in_buf], &ob = n->bufs[st.out_buf];
             rc = pn_launch_pool(ctx, n->prec, st.mode, ib.p, ob.p, B, ib.H, ib.W, st.C, ib.C, ob.C, st.out_coff, n->x3 ? ib.plane : 0, n->x3 ? ob.plane : 0, stream);
+        } else if (st.type == Step::BBLOCK) {
+            const ConvSpec &ca = n->convs[st.bb_a], &cb = n->convs[st.bb_b];
+            const Buf &ib = n->bufs[ca.in_buf], &ob = n->bufs[cb.out_buf];
+            BBProblem P;
+            memset(&P, 0, sizeof P);
+            P.in = ib.p; P.out = ob.p; P.wpack = st.bb_wpack; P.bias1 = st.bb_bias1; P.bias2 = st.bb_bias2;
+            P.B = B; P.H = ib.H; P.W = ib.W;
+            P.in_cs = ib.C; P.in_coff = ca.in_coff; P.out_cs = ob.C; P.out_coff = cb.out_coff;
+            P.Wt = st.bb_wt; P.tiles_x = (ib.W + st.bb_wt - 1) / st.bb_wt;
+            P.tiles_per_img = ((ib.H + 7) / 8) * P.tiles_x;
+            P.ntiles = B * P.tiles_per_img;
+            P.in_zero_off = (unsigned)((size_t)n->max_batch * ib.H * ib.W * ib.C * n->esize());
+            rc = pn_launch_bb64(ctx, P, stream);
         } else {
             rc = pn_launch_conv(ctx, st.launch, stream);
         }

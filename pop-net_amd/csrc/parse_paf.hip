@@ -617,7 +617,9 @@ extern "C" int pn_parse_reserve(pn_ctx *ctx, int max_batch) {
     if (max_batch < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_parse_reserve: max_batch must be >= 1");
     const size_t need = (size_t)max_batch * sizeof(ParseWs);
     if (ctx->parse_ws_bytes < need) {
-        if (ctx->parse_ws_fixed) return pn_set_error(ctx, PN_ERR_STATE, "pn_parse_reserve: the scratch size is already fixed at a smaller batch");
+        // an explicit reserve may grow the scratch (engines of different batch sizes share the per-device context); it is
+        // the caller's contract that no hipGraph captured on THIS context is still alive then -- graph-captured engines
+        // own private contexts (pipeline.StreamingEngine)
         if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
         ctx->parse_ws = nullptr;
         ctx->parse_ws_bytes = 0;

@@ -107,6 +107,19 @@ struct ConvLaunch {
 int pn_launch_conv(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);
 int pn_launch_conv3(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);     // conv3_inst_*.hip
 int pn_launch_conv4(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream);     // conv4_inst.hip
+
+// fused BasicBlock(64) (bb64_kernel.h): passed by value as the kernel argument
+struct BBProblem {
+    const void *in;        // NHWC bf16, channel stride in_cs, first channel in_coff (64 channels used)
+    void *out;             // NHWC bf16
+    const void *wpack;     // 36 x 4 KB
+    const float *bias1, *bias2;
+    int B, H, W;
+    int in_cs, in_coff, out_cs, out_coff;
+    int Wt, tiles_x, tiles_per_img, ntiles;
+    unsigned in_zero_off;  // byte offset from `in` to >= 16 zero bytes
+};
+int pn_launch_bb64(pn_ctx *ctx, const BBProblem &P, hipStream_t stream);       // bb64_inst.hip
 size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf, int rpg = 4);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
 int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 0 = no limit (direct staging)

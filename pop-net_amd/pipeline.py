@@ -66,7 +66,8 @@ class PoseEngine:
 
     def lock(self, locked=True):
         """Freeze the net's launch descriptors (call after a warm-up forward, before capturing a hipGraph)."""
-        self.ctx.check(self.L.pn_net_lock(self.net, 1 if locked else 0), "pn_net_lock")
+        net = self.net
+        (self.model._ctx or self.ctx).check(self.L.pn_net_lock(net, 1 if locked else 0), "pn_net_lock")
 
     # ---- stages (all asynchronous on the current stream) --------------------------------------
     def preprocess(self, depth):
@@ -87,9 +88,10 @@ class PoseEngine:
         return B
 
     def forward(self, B):
-        self.ctx.check(self.L.pn_rtpose_forward(self.net, C.c_void_p(self.x.data_ptr()), B, C.c_void_p(self.paf.data_ptr()),
-                                                C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.z.data_ptr()),
-                                                _lib.current_stream_ptr(self.device)), "pn_rtpose_forward")
+        net = self.net                                               # (the net reports errors through the context it was created on)
+        (self.model._ctx or self.ctx).check(self.L.pn_rtpose_forward(net, C.c_void_p(self.x.data_ptr()), B, C.c_void_p(self.paf.data_ptr()),
+                                                                     C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.z.data_ptr()),
+                                                                     _lib.current_stream_ptr(self.device)), "pn_rtpose_forward")
 
     def parse(self, B, frames=None, wire=None):
         """wire: optional device uint8 tensor [>= B, sizeof(pn_pose_wire)] that receives the compact records in the same launch."""
@@ -163,8 +165,9 @@ class YoloEngine:
     lock = PoseEngine.lock
 
     def forward(self, B):
-        self.ctx.check(self.L.pn_yolo_forward(self.net, C.c_void_p(self.x.data_ptr()), B, C.c_void_p(self.out.data_ptr()),
-                                              _lib.current_stream_ptr(self.device)), "pn_yolo_forward")
+        net = self.net
+        (self.model._ctx or self.ctx).check(self.L.pn_yolo_forward(net, C.c_void_p(self.x.data_ptr()), B, C.c_void_p(self.out.data_ptr()),
+                                                                   _lib.current_stream_ptr(self.device)), "pn_yolo_forward")
 
     def parse(self, B, frames=None):
         frames = self.frames if frames is None else frames

@@ -35,7 +35,9 @@ def test_config2_4484_frame_sweep_sharded_over_8_ranks(gpu):
     assert len(recs) == N and int((recs["status"] != 0).sum()) == 0
     # order / coverage: record i must be the record of frame i -- compare a spread sample (incl. both ends and the ragged
     # tail of the last rank) with a plain engine on exactly that frame
-    eng = se.engines[0]
+    with pytest.raises(_lib.PopnetError, match="locked"):       # the captured engines are frozen at their batch size (pn_net_lock)
+        se.engines[0].predict(torch.from_numpy(frames.load(0)[None]).to(gpu))
+    eng = PoseEngine(precision="fp32", device=gpu, max_batch=1)   # same seeded + calibrated weights, its own net
     sample = [0, 1, 7, 8, 63, 64, 65, 1000, 2241, 4470, 4476, 4477, 4483]
     for i in sample:
         one = eng.predict(torch.from_numpy(frames.load(i)[None]).to(gpu)).cpu().numpy().view(_lib.POSE_FRAME_DTYPE).reshape(-1)[0]
