@@ -9,7 +9,7 @@
 // y) in memory-bound prologue / epilogue phases that every resident block runs in lockstep (45 us per conv for 12 us of
 // MFMA work, profiles/README.md r01 v21).  Here the intermediate never leaves the CU and x is read once:
 //   * one PERSISTENT workgroup per CU walks its share of the 8-row x <=28-column output tiles;
-//   * per tile the 12 x 32-pixel input halo (48 KB, half-major [half][row][32 px][64 B]) sits in LDS, conv1 is evaluated on
+//   * per tile the 12 x 32-pixel input halo (48 KB, quarter-major [quarter][row][32 px][32 B]) sits in LDS, conv1 is evaluated on
 //     the 10 x 30 intermediate halo (1.34x recompute) straight into a second LDS image (40 KB, zero outside the map =
 //     conv2's padding), conv2 reads that image, the residual comes from the CENTRE of the input image (no second read
 //     of x), and y leaves with 16-B stores;
@@ -20,21 +20,36 @@
 //     k-step per phase, W1 | W2 as one periodic 36-step stream; input image pieces) and count their own vmcnt -- a
 //     compute wave's instruction stream is MFMA + ds_read only (conv4_kernel's ablations: DMA issue and its waits cost a
 //     lone wave 80 of 717 cycles per k-step);
-//   * one barrier per k-step, 148 KB of LDS, one workgroup per CU.
+//   * one barrier per k-step (a bare s_barrier for the compute waves: their fragment reads stay in flight across it), 152 KB
+//     of LDS, one workgroup per CU.
 // Weight pack (net.hip): [36 k-steps = (conv, half, tap)][4 cout tiles][64 lanes][8 bf16], rows permuted with
 // pn_conv_row_channel(tile, row, 4) so that a lane's 16 accumulators are 16 consecutive channels.
 #pragma once
 #include "conv3_kernel.h"
 
 
-#define BB_INHALF (12 * 32 * 64)
-#define BB_IN (2 * BB_INHALF)                 // 48 KB
-#define BB_MIDHALF (10 * 32 * 64)
-#define BB_MID (2 * BB_MIDHALF)               // 40 KB
+// LDS images are QUARTER-major: [4 quarters of 16 channels][row][32 px][32 B].  A lane's 16-B B fragment (8 channels) is
+// half of a pixel's 32-B quarter entry, so the 16 lanes one ds_read_b128 phase serves (8 with an even, 8 with an odd lane
+// quarter q) cover 8 consecutive pixels x 32 B = one whole 256-B bank row: conflict-free, where the half-major image of
+// conv3 / conv4 ([row][px][64 B]) costs 2 LDS cycles per read -- this kernel's 4 compute waves would keep the LDS array
+// ~100 % busy with it (20 MFMAs per 9 fragment reads).  One DMA instruction = one 32-pixel row of one quarter.
+#define BB_INQ (12 * 32 * 32)
+#define BB_IN (4 * BB_INQ)                    // 48 KB
+#define BB_MIDQ (10 * 32 * 32)
+#define BB_MID (4 * BB_MIDQ)                  // 40 KB
 #define BB_ASLOT 4096
 #define BB_OFF_MID (2 * BB_IN)
 #define BB_OFF_A (BB_OFF_MID + BB_MID)
-#define BB_LDS (BB_OFF_A + 3 * BB_ASLOT)      // 151552 B
+#define BB_NSLOT 4                              // weight ring: k-step ph + 3 lands in the slot whose last reader finished a full phase ago
+#define BB_LDS (BB_OFF_A + BB_NSLOT * BB_ASLOT) // 155648 B
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+// ReLU of two packed bf16: the sign bit of a bf16 is the sign bit of the int16 with the same bits
+__device__ __forceinline__ unsigned bb_relu_pk(unsigned w) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), i16x2{0, 0}));
+}
 
 __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
     typedef __bf16 T;
@@ -65,14 +80,14 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         auto dma_in = [&](int t, int buf, int j) {             // piece n = lw * 12 + j of tile t's input image -> IN[buf]
             int b, oy0, ox0, R, Wc;
             tile_geom(t, b, oy0, ox0, R, Wc);
-            const int n = lw * 12 + j;
-            const int half = n / 24, row = (n % 24) >> 1, g = n & 1;
-            const int px = g * 16 + (lane >> 2);
+            const int n = lw * 12 + j;                        // quarter lw, halo row j: 32 pixels x 32 B
+            const int qu = n / 12, row = n % 12;
+            const int px = lane >> 1;
             const int iy = oy0 - 2 + row, ix = ox0 - 2 + px;
             const size_t frame_b = ((size_t)b * H * W * P.in_cs + P.in_coff) * 2;
             const bool inb = px < Wc + 4 && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
-            const unsigned off = inb ? (unsigned)((iy * W + ix) * P.in_cs * 2 + half * 64 + (lane & 3) * 16) : P.in_zero_off - (unsigned)frame_b;
-            pn_glds16_s<0>((const char *)P.in + frame_b, off, (unsigned)__builtin_amdgcn_readfirstlane(buf * BB_IN + half * BB_INHALF + (row * 32 + g * 16) * 64));
+            const unsigned off = inb ? (unsigned)((iy * W + ix) * P.in_cs * 2 + qu * 32 + (lane & 1) * 16) : P.in_zero_off - (unsigned)frame_b;
+            pn_glds16_s<0>((const char *)P.in + frame_b, off, (unsigned)__builtin_amdgcn_readfirstlane(buf * BB_IN + qu * BB_INQ + row * 1024));
         };
         int t = blockIdx.x;
         if (t >= P.ntiles) return;
@@ -86,10 +101,18 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             const int tn = t + (int)gridDim.x < P.ntiles ? t + (int)gridDim.x : t;      // past the last tile: a harmless refetch into the idle image
 #pragma clang loop unroll(full)
             for (int ph = 0; ph < 36; ++ph) {
+#ifndef BB_FAKE_NODMA_IN                               // -DBB_FAKE_*: timing-only ablations (wrong results), scripts/bblab.hip
                 if (ph < 12) dma_in(tn, cur ^ 1, ph);
-                dma_a((ph + 3) % 36, ph % 3);
+#endif
+#ifndef BB_FAKE_NODMA_A
+                dma_a((ph + 3) % 36, (ph + 3) % BB_NSLOT);
+#endif
+#if defined(BB_FAKE_NODMA_IN) || defined(BB_FAKE_NODMA_A)
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#else
                 if (ph < 12) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+#endif
                 if (ph == 17) asm volatile("s_barrier" ::: "memory");          // the compute waves publish the intermediate image
             }
             asm volatile("s_barrier" ::: "memory");                             // end of tile: residual reads of IN[cur] are done
@@ -113,9 +136,11 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
     for (int ct = 0; ct < CT; ++ct) aq[0][ct] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ct * 1024);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int cur = 0;
-    for (; t < P.ntiles; t += gridDim.x) {
+    PN_STAMP_AT(0);
+    for (int it = 0; t < P.ntiles; t += gridDim.x, ++it) {
         int b, oy0, ox0, R, Wc;
         tile_geom(t, b, oy0, ox0, R, Wc);
+        if (it == 2) PN_STAMP_AT(1);                     // third tile: steady state
         const int MC = Wc + 2, nmid = (R + 2) * MC, nout = R * Wc;
         const float inv_mc = 1.0f / (float)MC, inv_wc = 1.0f / (float)Wc;
         const int inb = cur * BB_IN;
@@ -125,13 +150,13 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         for (int pt = 0; pt < PT1; ++pt) {
             const int s0 = (wave * PT1 + pt) * 16 + c, s = s0 < nmid ? s0 : 0;
             const int r = (int)(((float)s + 0.5f) * inv_mc), x = s - r * MC;
-            ba1[pt] = inb + q * 16 + (r * 32 + x) * 64;
+            ba1[pt] = inb + (q >> 1) * BB_INQ + (q & 1) * 16 + (r * 32 + x) * 32;
         }
 #pragma unroll
         for (int pt = 0; pt < PT2; ++pt) {
             const int s0 = (wave * PT2 + pt) * 16 + c, s = s0 < nout ? s0 : 0;
             const int r = (int)(((float)s + 0.5f) * inv_wc), x = s - r * Wc;
-            ba2[pt] = BB_OFF_MID + q * 16 + (r * 32 + x) * 64;
+            ba2[pt] = BB_OFF_MID + (q >> 1) * BB_MIDQ + (q & 1) * 16 + (r * 32 + x) * 32;
         }
         f32x4 acc[CT][PT1];
 #pragma unroll
@@ -140,8 +165,8 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             for (int pt = 0; pt < PT1; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
         // (aq[0] holds k-step 0's weight fragments: read in the prologue / prefetched by the previous tile's last phase)
         // ---------------- conv1: 18 k-steps on the input image ----------------
-#define BB_TAPOFF(tap) ((((tap) / 3) * 32 + ((tap) % 3)) * 64)
-#define BB_OFF1(j) ((((j) / PT1) / KK) * BB_INHALF + BB_TAPOFF(((j) / PT1) % KK))
+#define BB_TAPOFF(tap) ((((tap) / 3) * 32 + ((tap) % 3)) * 32)
+#define BB_OFF1(j) ((((j) / PT1) / KK) * 2 * BB_INQ + BB_TAPOFF(((j) / PT1) % KK))
 #pragma unroll
         for (int j = 0; j < BQ - 1; ++j) bq[j] = *reinterpret_cast<const bf16x8 *>(smem + ba1[j % PT1] + BB_OFF1(j));
 #pragma clang loop unroll(full)
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             for (int pt = 0; pt < PT1; ++pt) {
                 const int j = ph * PT1 + pt, jr = j + BQ - 1;
                 if (pt < CT)
-                    aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % 3) * BB_ASLOT + pt * 1024);
+                    aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % BB_NSLOT) * BB_ASLOT + pt * 1024);
                 if (jr < 18 * PT1) bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + ba1[jr % PT1] + BB_OFF1(jr));
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
@@ -161,8 +186,10 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // (no lgkmcnt wait: the ring slot refilled after this barrier was last read a phase ago, the images are stable)
+            asm volatile("s_barrier" ::: "memory");
         }
+        if (it == 2) PN_STAMP_AT(2);
         // ---------------- intermediate: bias + ReLU -> bf16 -> LDS image (zero outside the map) ----------------
 #pragma clang loop unroll(full)
         for (int pt = 0; pt < PT1; ++pt) {
@@ -170,24 +197,32 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             const int r = (int)(((float)s + 0.5f) * inv_mc), x = s - r * MC;
             const int my = oy0 - 1 + r, mx = ox0 - 1 + x;
             const bool inside = (unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W;
-            T ov[16];
+            const bool border = oy0 == 0 || ox0 == 0 || oy0 + R >= H || ox0 + Wc >= W;        // wave-uniform
+            // bias + ReLU as add + max, two channels per v_cvt_pk_bf16_f32; the zero padding outside the map is applied to the
+            // 8 packed dwords (per pixel), not per channel: a lone wave pays every VALU instruction of this block in full
+            // ReLU on the PACKED bf16 pair (a negative bf16 is a negative int16: one v_pk_max_i16 per two channels; rounding is
+            // monotonic, so relu(bf16(v)) == bf16(relu(v)))
+            u32x4 o0, o1;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc[ct][pt][i] + b1[4 * ct + i];
-                    v = v > 0.f ? v : 0.f;
-                    ov[4 * ct + i] = (T)(inside ? v : 0.f);
-                }
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x2 lo = {acc[ct][pt][0] + b1[4 * ct + 0], acc[ct][pt][1] + b1[4 * ct + 1]};
+                f32x2 hi = {acc[ct][pt][2] + b1[4 * ct + 2], acc[ct][pt][3] + b1[4 * ct + 3]};
+                const unsigned w0 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)));
+                const unsigned w1 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
+                if (ct < 2) { o0[2 * ct] = w0; o0[2 * ct + 1] = w1; }
+                else { o1[2 * ct - 4] = w0; o1[2 * ct - 3] = w1; }
+            }
+            if (border && !inside) { o0 = u32x4{0u, 0u, 0u, 0u}; o1 = o0; }      // conv2's zero padding; interior tiles skip the test
             if (s < nmid) {
-                u32x4 *dst = reinterpret_cast<u32x4 *>(smem + BB_OFF_MID + (q >> 1) * BB_MIDHALF + (r * 32 + x) * 64 + (q & 1) * 32);
-                dst[0] = reinterpret_cast<u32x4 *>(ov)[0];
-                dst[1] = reinterpret_cast<u32x4 *>(ov)[1];
+                u32x4 *dst = reinterpret_cast<u32x4 *>(smem + BB_OFF_MID + q * BB_MIDQ + (r * 32 + x) * 32);
+                dst[0] = o0;
+                dst[1] = o1;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (it == 2) PN_STAMP_AT(3);
         // ---------------- conv2: 18 k-steps on the intermediate image ----------------
-#define BB_OFF2(j) ((((j) / PT2) / KK) * BB_MIDHALF + BB_TAPOFF(((j) / PT2) % KK))
+#define BB_OFF2(j) ((((j) / PT2) / KK) * 2 * BB_MIDQ + BB_TAPOFF(((j) / PT2) % KK))
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -201,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
 #pragma clang loop unroll(full)
             for (int pt = 0; pt < PT2; ++pt) {
                 const int j = p2 * PT2 + pt, jr = j + BQ - 1;
-                aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % 3) * BB_ASLOT + pt * 1024);
+                aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % BB_NSLOT) * BB_ASLOT + pt * 1024);
                 if (jr < 18 * PT2) bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + ba2[jr % PT2] + BB_OFF2(jr));
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
@@ -211,8 +246,9 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
         }
+        if (it == 2) PN_STAMP_AT(4);
         // ---------------- output: bias + residual (centre of the input image) + ReLU, 2 x 16-B stores per pixel ----------------
         {
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -222,28 +258,33 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 const int s = (wave * PT2 + pt) * 16 + c;
                 const int r = (int)(((float)s + 0.5f) * inv_wc), x = s - r * Wc;
                 const bool valid = s < nout;
-                const u32x4 *rp = reinterpret_cast<const u32x4 *>(smem + inb + (q >> 1) * BB_INHALF + (((valid ? r : 0) + 2) * 32 + (valid ? x : 0) + 2) * 64 + (q & 1) * 32);
-                T rv[16];
-                reinterpret_cast<u32x4 *>(rv)[0] = rp[0];
-                reinterpret_cast<u32x4 *>(rv)[1] = rp[1];
-                T ov[16];
+                const u32x4 *rp = reinterpret_cast<const u32x4 *>(smem + inb + q * BB_INQ + (((valid ? r : 0) + 2) * 32 + (valid ? x : 0) + 2) * 32);
+                const u32x4 r0 = rp[0], r1 = rp[1];
+                u32x4 o0, o1;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc[ct][pt][i] + b2[4 * ct + i];
-                        v += (float)rv[4 * ct + i];
-                        ov[4 * ct + i] = (T)(v > 0.f ? v : 0.f);
-                    }
+                for (int ct = 0; ct < CT; ++ct) {
+                    const unsigned ra = ct < 2 ? r0[2 * ct] : r1[2 * ct - 4], rb = ct < 2 ? r0[2 * ct + 1] : r1[2 * ct - 3];
+                    // a bf16 is the upper half of its float: residual channels by shift / mask, no conversion instruction
+                    f32x2 lo = {acc[ct][pt][0] + b2[4 * ct + 0] + __builtin_bit_cast(float, ra << 16),
+                                acc[ct][pt][1] + b2[4 * ct + 1] + __builtin_bit_cast(float, ra & 0xffff0000u)};
+                    f32x2 hi = {acc[ct][pt][2] + b2[4 * ct + 2] + __builtin_bit_cast(float, rb << 16),
+                                acc[ct][pt][3] + b2[4 * ct + 3] + __builtin_bit_cast(float, rb & 0xffff0000u)};
+                    const unsigned w0 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)));
+                    const unsigned w1 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
+                    if (ct < 2) { o0[2 * ct] = w0; o0[2 * ct + 1] = w1; }
+                    else { o1[2 * ct - 4] = w0; o1[2 * ct - 3] = w1; }
+                }
                 // out-of-range offset for the unused slots: the store is issued unconditionally and dropped by the hardware
                 const unsigned voff = valid ? (unsigned)(((oy0 + r) * W + ox0 + x) * P.out_cs * 2 + 32 * q) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4 *>(ov)[0], orsrc, voff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4 *>(ov)[1], orsrc, voff + 16u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o0, orsrc, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, orsrc, voff + 16u, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the loader may now refill this image's buffer
+        if (it == 2) PN_STAMP_AT(5);
         cur ^= 1;
     }
+    PN_STAMP_AT(12);
 #undef BB_OFF1
 #undef BB_OFF2
 #undef BB_TAPOFF
