@@ -216,6 +216,32 @@ int pn_parse_paf_wire(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, 
                       pn_pose_wire *wire_dev, void *hip_stream);
 size_t pn_sizeof_pose_wire(void);
 
+/* ---- training targets ----------------------------------------------------------
+ * The CPU data-loader work of the reference's training dataset, as device kernels:
+ *   pn_compose_depth      the z-buffer multi-person compositor of KDH3D_Keypoints.__getitem__
+ *                         (tpm/lib/datasets/datasets_kdh3d_rtpose_mpaug.py:231-266, CR line endings): per output frame up to S
+ *                         source frames fg_depth [B,S,H,W] (f16 / f32 metres) with foreground masks fg_mask [B,S,H,W]
+ *                         (uint8 0 / 1), the first n_src[b] of them used, pasted over bg [B,H,W]; out [B,H,W] f32.
+ *   pn_rasterize_targets  get_ground_truth (:318-401) = putGaussianMaps (heatmap.py:20-36) + putVecMaps (paf.py:18-69) +
+ *                         putJointZ (posemap.py:83-106): kp2d [B,Pmax,15,2] f32 joint positions in network-input pixels
+ *                         (as Resize leaves them), kp_z [B,Pmax,15] f64 joint depths (metres), n_persons [B],
+ *                         depth_resize [B,h,w] f32 (the clamped input at stride resolution) ->
+ *                         heat [B,16,h,w], paf [B,28,h,w], z [B,15,h,w] (normalised), fg [B,15,h,w]  f32 NCHW, h = input / stride. */
+typedef struct pn_target_cfg {
+    int input_x, input_y;      /* network input size (224) */
+    int stride;                /* 8 */
+    int z_radius;              /* 2   train_rtpose_light3d_kdh3d_mpaug.py default */
+    double sigma;              /* 7.0 pixels  datasets_kdh3d_rtpose_mpaug.py:357 */
+    double depth_max, depth_mean, depth_std;   /* 6, 3, 2 */
+} pn_target_cfg;
+void pn_target_cfg_default(pn_target_cfg *cfg);
+int pn_compose_depth(pn_ctx *ctx, const void *fg_depth_dev, const unsigned char *fg_mask_dev, const int *n_src_dev,
+                     const void *bg_dev, int depth_dtype, int B, int S, int H, int W, float depth_max, float *out_dev,
+                     void *hip_stream);
+int pn_rasterize_targets(pn_ctx *ctx, const float *kp2d_dev, const double *kp_z_dev, const int *n_persons_dev, int B, int Pmax,
+                         const float *depth_resize_dev, const pn_target_cfg *cfg, float *heat_dev, float *paf_dev,
+                         float *z_dev, float *fg_dev, void *hip_stream);
+
 /* ---- Yolo-Pose+ decode ----------------------------------------------------------------------
  * Replaces parse_prior_pose (tpm/lib/utils/prior_pose_align.py:10-168, pred_vis=False), quirks
  * included (candidate order anchor-major; suppression loop over rows 1..n-2; inclusive

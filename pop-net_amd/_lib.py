@@ -30,6 +30,12 @@ class PopnetError(RuntimeError):
     pass
 
 
+class TargetCfg(C.Structure):
+    """pn_target_cfg"""
+    _fields_ = [("input_x", C.c_int), ("input_y", C.c_int), ("stride", C.c_int), ("z_radius", C.c_int),
+                ("sigma", C.c_double), ("depth_max", C.c_double), ("depth_mean", C.c_double), ("depth_std", C.c_double)]
+
+
 class ParseCfg(C.Structure):
     """pn_parse_cfg"""
     _fields_ = [("thresh_heatmap", C.c_float), ("thresh_paf", C.c_float),
@@ -96,6 +102,9 @@ _SIGNATURES = {
     "pn_parse_cfg_default": (None, [C.POINTER(ParseCfg)]),
     "pn_parse_paf": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_parse_paf_wire": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(ParseCfg), _vp, _vp, _vp]),
+    "pn_target_cfg_default": (None, [C.POINTER(TargetCfg)]),
+    "pn_compose_depth": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "pn_rasterize_targets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, C.POINTER(TargetCfg), _vp, _vp, _vp, _vp, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_sizeof_pose_frame": (_sz, []),

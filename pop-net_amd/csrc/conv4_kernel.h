@@ -14,7 +14,8 @@
 //     (8 KB) are fetched ONCE per block by LDS-DMA into a 3-slot ring and shared by the two strips: 95 B per MFMA
 //     through the vector-memory path (weights + halo) instead of 146 + halo;
 //   * the two strips are independent 4-row x <= 28-column tiles (own halo images), so a 28-row map wastes nothing;
-//   * activations: half-major halo images as in conv3 ([halo row][32 px][64 B] per 32-channel half), double-buffered
+//   * activations: quarter-major halo images ([2 quarters][halo row][32 px][32 B] per 32-channel half: conflict-free
+//     fragment reads, see below), double-buffered
 //     per HALF (12 KB per strip and buffer): the next half's image is fetched, one DMA instruction per k-step, while
 //     the current half's 9 taps run -- no hand-over stall;
 //   * ONE barrier per k-step (28 MFMAs per wave), LDS-DMA kept in flight across it with counted vmcnt (the guide's
@@ -28,7 +29,8 @@
 
 #define PN4_ASLOT 8192                  // one k-step of weight fragments: 8 cout tiles x 1 KB
 #define PN4_ARING (3 * PN4_ASLOT)
-#define PN4_BSTRIP (6 * 32 * 64)        // one 32-channel half image of one strip: 6 halo rows x 32 px x 64 B
+#define PN4_BQUART (6 * 32 * 32)        // one 16-channel quarter plane of a strip image: 6 halo rows x 32 px x 32 B
+#define PN4_BSTRIP (2 * PN4_BQUART)     // one 32-channel half image of one strip
 #define PN4_BBUF (2 * PN4_BSTRIP)       // both strips
 #define PN4_LDS (PN4_ARING + 2 * PN4_BBUF)
 
@@ -86,20 +88,22 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
     const size_t frame_b = ((size_t)b * P.H * P.W * P.in_cs + P.in_coff) * 2;
     const char *img = (const char *)P.in + frame_b;                          // + hh * 64 per half (scalar)
     const unsigned zero_rel = P.in_zero_off - (unsigned)frame_b;                // zero page (>= 64 * halves + 16 bytes of zeros) relative to img
+    // QUARTER-major images ([2 quarters of 16 channels][halo row][32 px][32 B] per 32-channel half): the 16 lanes one
+    // ds_read_b128 phase serves (8 with an even, 8 with an odd lane quarter) cover 8 pixels x 32 B = a whole bank row,
+    // conflict-free, where the half-major image of conv3 ([row][px][64 B]) costs 2 LDS cycles per read.  One DMA
+    // instruction = one 32-pixel halo row of one quarter; wave wc fetches quarter wc (6 rows).
     unsigned boff[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        const int n = wc * 6 + j;
-        const int row = n >> 1, px = (n & 1) * 16 + (lane >> 2);
-        const int iy = iy0 + row, ix = ix0 + px;
+        const int px = lane >> 1;
+        const int iy = iy0 + j, ix = ix0 + px;
         const bool inb = px < HC && (unsigned)ix < (unsigned)P.W && (unsigned)iy < (unsigned)P.H;
-        boff[j] = inb ? (unsigned)((iy * P.W + ix) * P.in_cs * 2 + (lane & 3) * 16) : zero_rel;
+        boff[j] = inb ? (unsigned)((iy * P.W + ix) * P.in_cs * 2 + wc * 32 + (lane & 1) * 16) : zero_rel;
     }
     const int nhalves = nchunks * 2;
     auto dma_b = [&](int j, int buf, int hh) {       // piece j of half hh -> image `buf` of this strip
-        const int n = wc * 6 + j;
-        const unsigned dst = (unsigned)(PN4_ARING + buf * PN4_BBUF + ((n >> 1) * PITCH + (n & 1) * 16) * 64) +
-                             (unsigned)__builtin_amdgcn_readfirstlane(wp * PN4_BSTRIP);
+        const unsigned dst = (unsigned)(PN4_ARING + buf * PN4_BBUF + j * 1024) +
+                             (unsigned)__builtin_amdgcn_readfirstlane(wp * PN4_BSTRIP + wc * PN4_BQUART);
         pn_glds16_s<0>(img + (size_t)(hh < nhalves ? hh : 0) * 64, boff[j], dst);   // past the last half: a harmless refetch into the idle image
     };
 
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
         const int s = slot < npix ? slot : 0;
         const int ry = (int)(((float)s + 0.5f) * inv_wc);
         const int rx = s - ry * Wc;
-        baddr[pt] = PN4_ARING + wp * PN4_BSTRIP + q * 16 + (ry * PITCH + rx) * 64;
+        baddr[pt] = PN4_ARING + wp * PN4_BSTRIP + (q >> 1) * PN4_BQUART + (q & 1) * 16 + (ry * PITCH + rx) * 32;
     }
     const int aaddr = wc * 4096 + lane * 16;
     f32x4 acc[CT][PT];
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
     PN_STAMP_AT(2);
 
     // item j = (phase ph, pixel tile pt): B fragment of tap ph % 9 from image (ph / 9) & 1
-#define PN4_BOFF(j) (((((j) / PT) / KK) & 1) * PN4_BBUF + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 64)
+#define PN4_BOFF(j) (((((j) / PT) / KK) & 1) * PN4_BBUF + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 32)
     // B fragments are read BQ - 1 items (4 MFMAs each) ahead of their use: with 2 ahead a lone wave on its SIMD spent
     // 147 of 717 cycles per k-step waiting for LDS (profiles/README.md, conv4 ablations)
 #ifndef PN4_BQ
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
 #pragma clang loop unroll(full)
             for (int pt = 0; pt < PT; ++pt) {
                 const int slot = pt * 16 + c;
-                const unsigned t = (unsigned)(baddr[pt] - PN4_ARING - wp * PN4_BSTRIP) >> 6;     // ry * 32 + rx
+                const unsigned t = (unsigned)(baddr[pt] - PN4_ARING - wp * PN4_BSTRIP - (q >> 1) * PN4_BQUART) >> 5;     // ry * 32 + rx
                 const unsigned opix = pix0 + (t >> 5) * (unsigned)Wo + (t & 31u);
                 float v[LC];
 #pragma unroll

@@ -11,7 +11,7 @@ for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
 by = {}
 for k, v in agg.items():
-    m = re.match(r"void (conv3_kernel<[^>]+>|conv_mfma_kernel<1,[^>]+>)", k)      # bf16 instantiations only
+    m = re.match(r"(?:void )?(conv3_kernel<[^>]+>|conv_mfma_kernel<1,[^>]+>|conv4_kernel|bb64_kernel)", k)      # bf16 kernels only
     if not m or 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
         continue
     f = sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']); w = sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE'])

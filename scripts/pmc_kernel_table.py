@@ -11,6 +11,7 @@ tot = collections.defaultdict(collections.Counter)
 calls = collections.Counter()
 for path in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)):
     seen = set()
+    # (each --pmc pass is its own run: counters of different passes are combined per kernel NAME, as sums over the run)
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -611,14 +611,117 @@ def golden_script_metrics(net="rtpose"):
     print("F9: PCK2D %.3f PCK3D %.3f AP2D %.2f AP3D %.2f" % (np.nanmean(k2), np.nanmean(k3), a2[-1], a3[-1]))
 
 
+def golden_targets():
+    """F10: training targets.  (a) the reference's get_ground_truth (datasets_kdh3d_rtpose_mpaug.py:318-401 (CR)) on seeded
+    annotation sets -- called on a stand-in `self` that carries only the attributes the method reads, so no dataset files
+    are needed; (b) the reference dataset's __getitem__ itself (z-buffer compositor + Resize + clamp + depth_resize +
+    targets, :223-286 (CR)) on a tiny fake MP-3DHP training tree written to a temp dir, with `random` seeded."""
+    import importlib
+    import random
+    import types
+    from popnet_amd import synth
+    mod = importlib.import_module("lib.datasets.datasets_kdh3d_rtpose_mpaug")
+    K = mod.KDH3D_Keypoints
+    stub = types.SimpleNamespace(input_x=224, input_y=224, stride=8, strideZ=8, num_joints=15, z_radius=2,
+                                 limb_ids=mod.kp_connections(mod.get_keypoints()), joint_names=mod.get_keypoints())
+    stub.remove_illegal_joint = types.MethodType(K.remove_illegal_joint, stub)
+    out = {}
+    cases = [(0, 11), (1, 12), (3, 13), (5, 14), (2, 15)]
+    for ci, (P, seed) in enumerate(cases):
+        rng = np.random.default_rng(seed)
+        joints, depths = synth.planted_persons(rng, P) if P else (np.zeros((0, 15, 2)), np.zeros(0))
+        kp3 = np.concatenate([joints, np.broadcast_to(depths[:, None, None], (P, 15, 1)) + rng.normal(0, 0.05, (P, 15, 1))], 2) if P else np.zeros((0, 15, 3))
+        if P >= 2:
+            joints[1, 4] = [230.0, 50.0]                      # outside the input: joint and its limbs dropped
+            joints[0, 7] = [-3.0, 10.0]
+            joints[1, 11] = joints[1, 9]                      # zero-length limb
+            joints[0, 13] = [223.9, 223.9]                    # last cell, window clipped
+        if P == 5:
+            joints[3] = joints[2] + 4.0                       # two persons on top of each other: clamp at 1, paf averaging, nearest z
+            kp3[3, :, 2] = kp3[2, :, 2] - 0.4
+        if P == 2:                                            # integer / half-integer cell coordinates: round-half-even of the limb box
+            joints[0, 8] = [100.0, 100.0]; joints[0, 9] = [116.0, 132.0]; joints[1, 8] = [60.0, 20.0]; joints[1, 1] = [60.0, 68.0]
+        anns = [{"2d_joints": joints[p].tolist(), "3d_joints": kp3[p].tolist()} for p in range(P)]
+        dr = rng.uniform(-0.5, 6.5, (28, 28))
+        if P:
+            h, pf, z, fg = K.get_ground_truth(stub, anns, dr)
+        else:                                                 # the reference indexes keypoints_2d[:, :, 0]: no annotations = no call; targets of an empty frame
+            h = np.zeros((28, 28, 16)); h[:, :, 15] = 1.0
+            pf = np.zeros((28, 28, 28)); fg = np.zeros((28, 28, 15))
+            z = (np.clip(np.repeat(dr[:, :, None], 15, 2), 0, 6) - 3.0) / 2.0
+        out.update({"gt%d_kp2d" % ci: joints, "gt%d_kp3d" % ci: kp3, "gt%d_depth" % ci: dr, "gt%d_heat" % ci: h, "gt%d_paf" % ci: pf,
+                    "gt%d_z" % ci: z, "gt%d_fg" % ci: fg})
+    out["n_gt"] = np.array(len(cases))
+
+    # (b) the dataset class end to end on a fake tree
+    from lib.datasets import data_augmentation_2d3d as aug
+    d = tempfile.mkdtemp(prefix="popnet_mpaug_")
+    for sub in ("img", "seg", "bg"):
+        os.makedirs(os.path.join(d, sub))
+    rng = np.random.default_rng(77)
+    H, W = 320, 240                                           # (small frames keep the fixture small; the path is size-agnostic)
+    ann_files = []
+    for ii in range(5):                                       # five annotation sets (aug_mods indexes 0..4), two frames each
+        ann = {"intrinsics": dict(mod.intrinsics)}
+        for f in range(2):
+            name = "s%d_%d.npy" % (ii, f)
+            joints, depths = synth.planted_persons(rng, 1, size=224)
+            j2 = joints[0] * [W / 224.0, H / 224.0]
+            ann[name] = [{"2d_joints": j2.tolist(), "3d_joints": np.concatenate([j2, np.full((15, 1), depths[0])], 1).tolist()}]
+            depth = np.clip(rng.normal(depths[0], 0.1, (H, W)), 0.3, 5.9)
+            mask = np.zeros((H, W))
+            x0, x1 = int(j2[:, 0].min()) - 10, int(j2[:, 0].max()) + 10
+            y0, y1 = int(j2[:, 1].min()) - 10, int(j2[:, 1].max()) + 10
+            mask[max(y0, 0):y1, max(x0, 0):x1] = 1.0
+            np.save(os.path.join(d, "img", name), depth.astype(np.float16))
+            np.save(os.path.join(d, "seg", name), mask.astype(np.uint8))
+        path = os.path.join(d, "ann%d.json" % ii)
+        json.dump(ann, open(path, "w"))
+        ann_files.append(path)
+    bgs = {}
+    for f in range(2):
+        name = "bg%d.npy" % f
+        np.save(os.path.join(d, "bg", name), np.clip(rng.normal(4.5, 0.3, (H, W)), 0, 6).astype(np.float16))
+        bgs[str(f)] = {"file_name": name}
+    json.dump(bgs, open(os.path.join(d, "bg.json"), "w"))
+    random.seed(5)
+    ds = K(os.path.join(d, "img"), ann_files, preprocess=aug.Compose([aug.Cvt2ndarray(), aug.Resize(224)]), w_org=W, h_org=H,
+           input_x=224, input_y=224, stride=8, z_radius=2, bg_file=os.path.join(d, "bg.json"), bg_dir=os.path.join(d, "bg"), seg_dir=os.path.join(d, "seg"))
+    for idx in range(2):
+        # replay the item's random draws to record WHICH sources it composes (same generator state before and after)
+        st = random.getstate()
+        mod_id = random.randint(0, len(mod.aug_mods) - 1)
+        picks = []
+        for ii in mod.aug_mods[mod_id]:
+            if mod.uniform(0, 1) > 0.8:
+                continue
+            picks.append(ii)
+        if not picks:
+            picks.append(random.randint(0, len(ds.ids_list) - 1))
+        random.setstate(st)
+        image, heat, paf, z, fg, last2d, _ = ds[idx]
+        names = [ds.ids_list[ii][idx % len(ds.ids_list[ii])] for ii in picks]
+        bg_name = ds.bg_list[idx % ds.num_bg_images]["file_name"]
+        kp2d = np.array([np.array(ds.anno_dic_list[ii][nm][0]["2d_joints"]) for ii, nm in zip(picks, names)])
+        kp3d = np.array([np.array(ds.anno_dic_list[ii][nm][0]["3d_joints"]) for ii, nm in zip(picks, names)])
+        out.update({"it%d_fg_depth" % idx: np.stack([np.load(os.path.join(d, "img", nm)) for nm in names]),
+                    "it%d_fg_mask" % idx: np.stack([np.load(os.path.join(d, "seg", nm)) for nm in names]),
+                    "it%d_bg" % idx: np.load(os.path.join(d, "bg", bg_name)), "it%d_kp2d_org" % idx: kp2d, "it%d_kp3d" % idx: kp3d,
+                    "it%d_image" % idx: image.numpy(), "it%d_heat" % idx: heat.numpy(), "it%d_paf" % idx: paf.numpy(),
+                    "it%d_z" % idx: z.numpy(), "it%d_fg" % idx: fg.numpy()})
+    out["n_items"] = np.array(2)
+    np.savez_compressed(os.path.join(HERE, "targets.npz"), **out)
+    print("F10: targets.npz:", len(out), "arrays; persons per composed item", [out["it%d_kp3d" % i].shape[0] for i in range(2)])
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate golden vectors"
     install_shims()
     import popnet_amd  # noqa: F401
-    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo"]
+    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo", "targets"]
     fns = {"keys": golden_state_dicts, "forward": golden_forward, "parse": golden_parse, "yolo": golden_yolo,
            "pafprocess": golden_pafprocess, "script": golden_script,
            "script_yolo": golden_script_yolo, "metrics": golden_metrics, "script_metrics": golden_script_metrics,
-           "script_metrics_yolo": lambda: golden_script_metrics("yolo")}
+           "script_metrics_yolo": lambda: golden_script_metrics("yolo"), "targets": golden_targets}
     for w in which:
         fns[w]()
