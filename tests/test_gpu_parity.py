@@ -175,10 +175,11 @@ def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, mo
         assert torch.equal(got4_y, ref_y)
 
 
-@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0"])
+@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0", "POPNET_NO_BBLOCK=1"])
 def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, monkeypatch):
     """The experiment switches of profiles/README.md (224-pixel wave tiles, double-buffered halo images, 8-row tiles on
-    14-column maps) select other conv3_kernel instantiations of the same arithmetic: same maps, bit for bit, as the
+    14-column maps; conv4_kernel on every / no level; the two layer1 BasicBlocks as two launches each instead of the fused
+    bb64_kernel) select other kernels of the same arithmetic: same maps, bit for bit, as the
     default build of the net (rtpose at 224x224 with a ragged batch of 5; YoloPoseNet for its 14x14 layers)."""
     from popnet_amd.network.yolo_posenet import YoloPoseNet
     x = torch.from_numpy(np.random.default_rng(16).normal(0, 1, (5, 1, 224, 224)).astype(np.float32)).to(gpu)
