@@ -242,6 +242,50 @@ int pn_rasterize_targets(pn_ctx *ctx, const float *kp2d_dev, const double *kp_z_
                          const float *depth_resize_dev, const pn_target_cfg *cfg, float *heat_dev, float *paf_dev,
                          float *z_dev, float *fg_dev, void *hip_stream);
 
+/* ---- training step primitives (BASELINE configs[4]) ------------------------------
+ * fp32, NCHW, contiguous -- the layout of the reference's own tensors, so every intermediate can be laid next to the
+ * reference module's.  One entry per differentiable primitive of rtpose_light3d in train mode; popnet_amd/train.py
+ * strings them together (forward, rtpose_light3d_loss_fgweight, backward, Nesterov SGD).  All asynchronous on the stream.
+ *   pn_conv2d_forward   nn.Conv2d (tpm/lib/network/rtpose_light3d.py:31-40,144,232-246): kernel 1 / 3 / 7, any stride and
+ *                       padding; accumulate != 0 adds into y.  w [Cout, Cin, k, k], bias [Cout] or NULL.
+ *   pn_conv2d_dgrad     its input gradient (stride 1): dx [N,Cin,H,W] (+)= conv_transpose(dy [N,Cout,Ho,Wo], w)
+ *   pn_conv2d_wgrad     its weight (and bias, if dbias != NULL) gradient
+ *   pn_bn_train_forward nn.BatchNorm2d in train mode: batch statistics (biased variance, eps), running statistics updated
+ *                       with `momentum` (unbiased variance) when given, y = act(bn(x) + res); act = 0 none, 1 ReLU,
+ *                       2 LeakyReLU(0.1); res (BasicBlock identity, rtpose_light3d.py:66-67) or NULL
+ *   pn_bn_train_backward  gradient of the above: dy is the gradient w.r.t. y, out = y (for the activation mask);
+ *                       dres (or NULL) receives / accumulates the gradient of the residual input
+ *   pn_avgpool3s2_*     nn.AvgPool2d(3, 2, 1) (rtpose_light3d.py:152,158), planes = N * C
+ *   pn_head_forward     s = sigmoid(v); out = kind ? (s - 0.5) * 4 : s (rtpose_light3d.py:335-337) written with an image
+ *                       stride of out_ld channels (a slice of the stage-2 input, :339); *loss = mean(w (out - target)^2),
+ *                       w = 0.1 + 0.9 fg when fg != NULL (rtpose_light3d_loss_fgweight, losses.py:65-90)
+ *   pn_head_backward    dv = (d loss / d out + dextra) * d out / d v; dextra [N, dextra_ld, HW] slice or NULL
+ *   pn_slice_copy       torch.cat / its gradient: copy (or add) a [N, C, HW] tensor between channel slices
+ *   pn_sgd_nesterov     torch.optim.SGD(momentum, nesterov=True) on a flat buffer (train_rtpose_light3d_kdh3d_mpaug.py:313-316);
+ *                       grad_scale multiplies the gradient first (1 / world size after the all-reduce) */
+int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const float *bias_dev, float *y_dev, int N, int Cin,
+                      int H, int W, int Cout, int ks, int stride, int pad, int accumulate, void *hip_stream);
+int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float *dx_dev, int N, int Cin, int H, int W, int Cout,
+                    int ks, int pad, int accumulate, void *hip_stream);
+int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float *dw_dev, float *dbias_dev, int N, int Cin, int H,
+                    int W, int Cout, int ks, int stride, int pad, void *hip_stream);
+int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev, const float *beta_dev, const float *res_dev,
+                        float *y_dev, float *save_mean_dev, float *save_invstd_dev, float *running_mean_dev,
+                        float *running_var_dev, float momentum, float eps, int act, int N, int C, int HW, void *hip_stream);
+int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, const float *out_dev, const float *gamma_dev,
+                         const float *save_mean_dev, const float *save_invstd_dev, int act, int N, int C, int HW, float *dx_dev,
+                         float *dgamma_dev, float *dbeta_dev, float *dres_dev, int dres_accumulate, void *hip_stream);
+int pn_avgpool3s2_forward(pn_ctx *ctx, const float *x_dev, float *y_dev, int planes, int H, int W, void *hip_stream);
+int pn_avgpool3s2_backward(pn_ctx *ctx, const float *dy_dev, float *dx_dev, int planes, int H, int W, void *hip_stream);
+int pn_head_forward(pn_ctx *ctx, const float *v_dev, const float *target_dev, const float *fg_dev, int kind, int N, int C, int HW,
+                    float *s_dev, float *out_dev, int out_ld, float *loss_dev, void *hip_stream);
+int pn_head_backward(pn_ctx *ctx, const float *s_dev, const float *target_dev, const float *fg_dev, const float *dextra_dev,
+                     int dextra_ld, int kind, int N, int C, int HW, float *dv_dev, void *hip_stream);
+int pn_slice_copy(pn_ctx *ctx, const float *src_dev, int src_ld, float *dst_dev, int dst_ld, int N, int C, int HW, int accumulate,
+                  void *hip_stream);
+int pn_sgd_nesterov(pn_ctx *ctx, float *param_dev, const float *grad_dev, float *momentum_buf_dev, size_t n, float lr,
+                    float momentum, float weight_decay, int first_step, float grad_scale, void *hip_stream);
+
 /* ---- Yolo-Pose+ decode ----------------------------------------------------------------------
  * Replaces parse_prior_pose (tpm/lib/utils/prior_pose_align.py:10-168, pred_vis=False), quirks
  * included (candidate order anchor-major; suppression loop over rows 1..n-2; inclusive

@@ -105,6 +105,17 @@ _SIGNATURES = {
     "pn_target_cfg_default": (None, [C.POINTER(TargetCfg)]),
     "pn_compose_depth": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "pn_rasterize_targets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, C.POINTER(TargetCfg), _vp, _vp, _vp, _vp, _vp]),
+    "pn_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "pn_conv2d_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "pn_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "pn_bn_train_forward": (_i, [_vp] * 10 + [_f, _f] + [_i] * 4 + [_vp]),
+    "pn_bn_train_backward": (_i, [_vp] * 7 + [_i] * 4 + [_vp] * 4 + [_i, _vp]),
+    "pn_avgpool3s2_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pn_avgpool3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pn_head_forward": (_i, [_vp, _vp, _vp, _vp] + [_i] * 4 + [_vp, _vp, _i, _vp, _vp]),
+    "pn_head_backward": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 5 + [_vp, _vp]),
+    "pn_slice_copy": (_i, [_vp, _vp, _i, _vp] + [_i] * 5 + [_vp]),
+    "pn_sgd_nesterov": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _i, _f, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_sizeof_pose_frame": (_sz, []),

@@ -79,6 +79,7 @@ pn_ctx *pn_create(int device_id) {
 void pn_destroy(pn_ctx *ctx) {
     if (!ctx) return;
     if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
+    if (ctx->train_ws) (void)hipFree(ctx->train_ws);
     delete ctx;
 }
 

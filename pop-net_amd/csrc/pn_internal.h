@@ -13,6 +13,9 @@ struct pn_ctx {
     void *parse_ws = nullptr;
     size_t parse_ws_bytes = 0;
     bool parse_ws_fixed = false;     // pn_parse_reserve: the scratch never moves again
+    // scratch of the training kernels (flipped weights, split-reduction partials; train.hip), stream-ordered reuse
+    void *train_ws = nullptr;
+    size_t train_ws_bytes = 0;
 };
 
 int pn_set_error(pn_ctx *ctx, int code, const char *fmt, ...);

@@ -1,0 +1,657 @@
+// Training step kernels (BASELINE configs[4]): fp32, NCHW (the layout of the reference's tensors), one
+// C-ABI entry per differentiable primitive of rtpose_light3d in train mode.  The host side (popnet_amd/train.py) strings
+// them together in the order autograd would.
+//   conv forward / data gradient / weight gradient   implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains)
+//       nn.Conv2d of tpm/lib/network/rtpose_light3d.py:31-40,144-146,232-246 and its autograd
+//   train-mode BatchNorm2d (+ residual add + ReLU / LeakyReLU(0.1)) forward and backward      rtpose_light3d.py:52-70,147,244
+//   AvgPool2d(3, 2, 1) forward / backward                                                     rtpose_light3d.py:152,158
+//   sigmoid heads + rtpose_light3d_loss_fgweight forward and gradient                         rtpose_light3d.py:335-337, losses.py:65-106
+//   SGD with Nesterov momentum                                                                train_rtpose_light3d_kdh3d_mpaug.py:313-316
+// Roofline: the three GEMM-shaped kernels are MFMA-bound (fp32-input matrix peak 157 TFLOP/s), everything else HBM-bound.
+#include <cmath>
+#include "pn_internal.h"
+
+typedef float t_f32x4 __attribute__((ext_vector_type(4)));
+
+struct TConv {
+    const float *x;      // [N, Cin, H, W]
+    const float *w;      // [Cout, Cin * KS * KS]
+    const float *bias;   // [Cout] or nullptr
+    float *y;            // [N, Cout, Ho, Wo]
+    int N, Cin, H, W, Cout, Ho, Wo, stride, pad, accumulate;
+    int Kdim;            // Cin * KS * KS
+    int P;               // N * Ho * Wo
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward (and, with flipped weights, the stride-1 data gradient): D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],
+// k = (ci, ky, kx).  Block = 64 couts x 128 pixels, 4 waves (each 64 couts x 32 pixels = 4 x 2 MFMA tiles), K chunks of 16
+// staged through LDS (weights k-major, the gathered input k-major; lanes run along the pixels, so every global gather is a
+// run of consecutive addresses), next chunk's global loads in flight during the MFMAs of the current one.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TC_KC 16
+#define TC_AP 80      // LDS pitches: 4 k rows x 16 lanes of an MFMA operand read fall on 64 different banks
+#define TC_BP 144
+
+template <int KS>
+__global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
+    __shared__ float As[TC_KC][TC_AP];
+    __shared__ float Bs[TC_KC][TC_BP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int p0 = blockIdx.x * 128, co0 = blockIdx.y * 64;
+    const int HoWo = c.Ho * c.Wo;
+    // staging roles
+    const int b_pn = t & 127, b_k0 = t >> 7;            // B: pixel column, k rows b_k0 + 2j
+    const int a_co = t & 63, a_k0 = (t >> 6) * 4;       // A: cout row, k rows a_k0 + j
+    const int bp = p0 + b_pn;
+    const bool bp_ok = bp < c.P;
+    int bn = 0, iy0 = 0, ix0 = 0;
+    if (bp_ok) {
+        bn = bp / HoWo;
+        const int rem = bp - bn * HoWo, oy = rem / c.Wo, ox = rem - oy * c.Wo;
+        iy0 = oy * c.stride - c.pad;
+        ix0 = ox * c.stride - c.pad;
+    }
+    const float *xb = c.x + (size_t)bn * c.Cin * c.H * c.W;
+    const bool a_ok = co0 + a_co < c.Cout;
+    const float *wa = c.w + (size_t)(co0 + a_co) * c.Kdim;
+
+    float ra[4], rb[8];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + a_k0 + j;
+            ra[j] = (a_ok && k < c.Kdim) ? wa[k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + b_k0 + 2 * j;
+            const int ci = k / (KS * KS), rr = k - ci * (KS * KS), ky = rr / KS, kx = rr - ky * KS;
+            const int iy = iy0 + ky, ix = ix0 + kx;
+            const bool ok = bp_ok && k < c.Kdim && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W;
+            rb[j] = ok ? xb[((size_t)ci * c.H + iy) * c.W + ix] : 0.f;
+        }
+    };
+    t_f32x4 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load(0);
+    for (int k0 = 0; k0 < c.Kdim; k0 += TC_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[a_k0 + j][a_co] = ra[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[b_k0 + 2 * j][b_pn] = rb[j];
+        __syncthreads();
+        if (k0 + TC_KC < c.Kdim) load(k0 + TC_KC);
+#pragma unroll
+        for (int ks = 0; ks < TC_KC / 4; ++ks) {
+            float a[4], b[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = As[4 * ks + q][16 * m + r];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = Bs[4 * ks + q][32 * wave + 16 * n + r];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    // epilogue: lane holds couts 16m + 4q + i of pixel 32 wave + 16 n + r
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int p = p0 + 32 * wave + 16 * n + r;
+        if (p >= c.P) continue;
+        const int img = p / HoWo, rem = p - img * HoWo;
+        float *yb = c.y + (size_t)img * c.Cout * HoWo + rem;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * m + 4 * q + i;
+                if (co >= c.Cout) continue;
+                float v = acc[m][n][i];
+                if (c.bias) v += c.bias[co];
+                float *o = yb + (size_t)co * HoWo;
+                *o = c.accumulate ? *o + v : v;
+            }
+    }
+}
+
+// Weights for the data gradient: Wt[ci][(co, ky', kx')] = W[co][ci][KS-1-ky'][KS-1-kx']
+__global__ void wflip_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cout, int Cin, int KS) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int KK = KS * KS, total = Cout * Cin * KK;
+    if (i >= total) return;
+    const int ci = i / (Cout * KK), rem = i - ci * Cout * KK, co = rem / KK, rr = rem - co * KK;
+    wt[i] = w[((size_t)co * Cin + ci) * KK + (KK - 1 - rr)];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient: dW[cout][k] = sum_pixels dY[cout][pixel] * X[k][pixel].  Block = 64 couts x 64 k columns over one slice of
+// the pixels (grid.z slices -> partial sums, reduced in slice order by wgrad_reduce_kernel: deterministic, no atomics);
+// reduction chunks of 32 pixels, lanes along the pixels for both operands.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TW_RC 32
+#define TW_P 81
+
+template <int KS>
+__global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__restrict__ partial, int pix_per_slice) {
+    __shared__ float As[TW_RC][TW_P];      // dY  [pixel][cout]
+    __shared__ float Bs[TW_RC][TW_P];      // X   [pixel][k column]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int kc0 = blockIdx.x * 64, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    const int HoWo = c.Ho * c.Wo;
+    const int pl = t & 31, g = t >> 5;
+    int kci[8], kky[8], kkx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kc0 + g + 8 * j;
+        if (k < c.Kdim) {
+            kci[j] = k / (KS * KS);
+            const int rr = k - kci[j] * (KS * KS);
+            kky[j] = rr / KS;
+            kkx[j] = rr - kky[j] * KS;
+        } else {
+            kci[j] = -1; kky[j] = 0; kkx[j] = 0;
+        }
+    }
+    const int pbeg = slice * pix_per_slice, pend = min(pbeg + pix_per_slice, c.P);
+    float ra[8], rb[8];
+    auto load = [&](int pc) {
+        const int p = pc + pl;
+        const bool ok = p < pend;
+        int img = 0, rem = 0, oy = 0, ox = 0;
+        if (ok) {
+            img = p / HoWo;
+            rem = p - img * HoWo;
+            oy = rem / c.Wo;
+            ox = rem - oy * c.Wo;
+        }
+        const float *dyb = c.y + (size_t)img * c.Cout * HoWo + rem;
+        const float *xb = c.x + (size_t)img * c.Cin * c.H * c.W;
+        const int iy0 = oy * c.stride - c.pad, ix0 = ox * c.stride - c.pad;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int co = co0 + g + 8 * j;
+            ra[j] = (ok && co < c.Cout) ? dyb[(size_t)co * HoWo] : 0.f;
+            const int iy = iy0 + kky[j], ix = ix0 + kkx[j];
+            const bool okb = ok && kci[j] >= 0 && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W;
+            rb[j] = okb ? xb[((size_t)kci[j] * c.H + iy) * c.W + ix] : 0.f;
+        }
+    };
+    t_f32x4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (pbeg < pend) load(pbeg);
+    for (int pc = pbeg; pc < pend; pc += TW_RC) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            As[pl][g + 8 * j] = ra[j];
+            Bs[pl][g + 8 * j] = rb[j];
+        }
+        __syncthreads();
+        if (pc + TW_RC < pend) load(pc + TW_RC);
+#pragma unroll
+        for (int ks = 0; ks < TW_RC / 4; ++ks) {
+            const float a = As[4 * ks + q][16 * wave + r];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[4 * ks + q][16 * n + r], acc[n], 0, 0, 0);
+        }
+    }
+    float *pb = partial + (size_t)slice * c.Cout * c.Kdim;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int k = kc0 + 16 * n + r;
+        if (k >= c.Kdim) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + 16 * wave + 4 * q + i;
+            if (co < c.Cout) pb[(size_t)co * c.Kdim + k] = acc[n][i];
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, int n, int slices) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += partial[(size_t)k * n + i];
+    dw[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Reductions per channel over (N, HW): grid (C, slices) partial sums in double, then a one-block-per-channel finish.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double t_block_sum(double v, double *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
+    return s;      // valid on thread 0
+}
+
+// MODE 0: sum x, sum x^2 (BN statistics).  MODE 1: sum g, sum g * (x - mean) with g = dy * act'(out) (BN backward).
+// MODE 2: sum dy (bias gradient).
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
+                                                           const float *__restrict__ mean, int act, int N, int C, int HW, int slices,
+                                                           double *__restrict__ partial) {
+    __shared__ double sh[4];
+    const int ch = blockIdx.x, sl = blockIdx.y;
+    const long total = (long)N * HW, per = (total + slices - 1) / slices;
+    const long beg = sl * per, end = min(beg + per, total);
+    const float mu = MODE == 1 ? mean[ch] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
+    for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const long n = i / HW, p = i - n * HW;
+        const size_t off = ((size_t)n * C + ch) * HW + p;
+        if (MODE == 0) {
+            const double v = x[off];
+            s0 += v; s1 += v * v;
+        } else if (MODE == 1) {
+            float g = dy[off];
+            if (act == PN_ACT_RELU) g = out[off] > 0.f ? g : 0.f;
+            else if (act == PN_ACT_LEAKY) g = out[off] > 0.f ? g : g * 0.1f;
+            s0 += g; s1 += (double)g * (double)(x[off] - mu);
+        } else {
+            s0 += dy[off];
+        }
+    }
+    const double r0 = t_block_sum(s0, sh);
+    const double r1 = t_block_sum(s1, sh);
+    if (threadIdx.x == 0) {
+        partial[((size_t)ch * slices + sl) * 2] = r0;
+        partial[((size_t)ch * slices + sl) * 2 + 1] = r1;
+    }
+}
+
+__global__ void bn_stats_finish_kernel(const double *__restrict__ partial, int C, int slices, double count, float eps, float momentum,
+                                       float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ running_mean,
+                                       float *__restrict__ running_var) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[ch] = (float)mean;
+    save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * (count / (count - 1.0)));
+}
+
+__global__ void sums_finish_kernel(const double *__restrict__ partial, int C, int slices, float *__restrict__ out0, float *__restrict__ out1,
+                                   const float *__restrict__ invstd) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    if (out0) out0[ch] = (float)s;                                     // d beta / d bias
+    if (out1) out1[ch] = (float)(invstd ? ss * (double)invstd[ch] : ss);   // d gamma = sum g (x - mean) * invstd
+}
+
+__global__ void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ res, int act,
+                                int C, int HW, size_t total, float *__restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)((i / HW) % C);
+    float v = (x[i] - mean[ch]) * invstd[ch] * gamma[ch] + beta[ch];
+    if (res) v += res[i];
+    if (act == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (act == PN_ACT_LEAKY) v = v > 0.f ? v : v * 0.1f;
+    y[i] = v;
+}
+
+// dx = gamma * invstd * (g - sum_g / n - (x - mean) * invstd^2 * sum_gx / n);  dres (+)= g   (identity path of a BasicBlock)
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
+                                    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                    const double *__restrict__ partial, int slices, int act, int C, int HW, size_t total, double count,
+                                    float *__restrict__ dx, float *__restrict__ dres, int dres_accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)((i / HW) % C);
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    float g = dy[i];
+    if (act == PN_ACT_RELU) g = out[i] > 0.f ? g : 0.f;
+    else if (act == PN_ACT_LEAKY) g = out[i] > 0.f ? g : g * 0.1f;
+    const float is = invstd[ch];
+    const float mg = (float)(s / count), k2 = (float)(ss / count) * is * is;
+    dx[i] = (g - mg - (x[i] - mean[ch]) * k2) * is * gamma[ch];
+    if (dres) dres[i] = dres_accumulate ? dres[i] + g : g;
+}
+
+// AvgPool2d(3, stride 2, padding 1), count_include_pad = True
+__global__ void avgpool_fwd_kernel(const float *__restrict__ x, int H, int W, int Ho, int Wo, size_t total, float *__restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+    const size_t plane = i / ((size_t)Wo * Ho);
+    const float *xp = x + plane * H * W;
+    float s = 0.f;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) s += xp[(size_t)iy * W + ix];
+        }
+    y[i] = s / 9.f;
+}
+
+__global__ void avgpool_bwd_kernel(const float *__restrict__ dy, int H, int W, int Ho, int Wo, size_t total, float *__restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ix = (int)(i % W), iy = (int)((i / W) % H);
+    const size_t plane = i / ((size_t)W * H);
+    const float *dp = dy + plane * Ho * Wo;
+    float s = 0.f;
+    for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy)         // outputs whose window [2oy-1, 2oy+1] holds iy
+        for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox)
+            if (oy < Ho && ox < Wo) s += dp[(size_t)oy * Wo + ox];
+    dx[i] = s / 9.f;
+}
+
+// Heads: s = sigmoid(v); out = kind ? (s - 0.5) * 4 : s  (rtpose_light3d.py:335-337), written into a channel slice of the
+// stage-2 input when out_ld > C (torch.cat, :339); loss partials sum w (out - t)^2 per block.
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ v, const float *__restrict__ target, const float *__restrict__ fg, int kind,
+                                                       int C, int HW, size_t total, float *__restrict__ s_out, float *__restrict__ out, int out_ld,
+                                                       double *__restrict__ partial) {
+    __shared__ double sh[4];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0.0;
+    if (i < total) {
+        const float s = 1.f / (1.f + expf(-v[i]));
+        const float o = kind ? (s - 0.5f) * 4.f : s;
+        s_out[i] = s;
+        const size_t n = i / ((size_t)C * HW), rem = i - n * (size_t)C * HW;
+        out[n * (size_t)out_ld * HW + rem] = o;
+        const float d = o - target[i];
+        const float w = fg ? 0.1f + fg[i] * 0.9f : 1.f;
+        e = (double)(d * d * w);
+    }
+    const double r = t_block_sum(e, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void loss_finish_kernel(const double *__restrict__ partial, int nblocks, double numel, float *__restrict__ loss) {
+    if (threadIdx.x || blockIdx.x) return;
+    double s = 0.0;
+    for (int i = 0; i < nblocks; ++i) s += partial[i];
+    *loss = (float)(s / numel);
+}
+
+// dv = (2 w (out - t) / numel + dextra) * (kind ? 4 : 1) * s (1 - s)
+__global__ void head_bwd_kernel(const float *__restrict__ s_in, const float *__restrict__ target, const float *__restrict__ fg, const float *__restrict__ dextra,
+                                int dextra_ld, int kind, int C, int HW, size_t total, float inv_numel, float *__restrict__ dv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float s = s_in[i];
+    const float o = kind ? (s - 0.5f) * 4.f : s;
+    const float w = fg ? 0.1f + fg[i] * 0.9f : 1.f;
+    float g = 2.f * (o - target[i]) * w * inv_numel;
+    if (dextra) {
+        const size_t n = i / ((size_t)C * HW), rem = i - n * (size_t)C * HW;
+        g += dextra[n * (size_t)dextra_ld * HW + rem];
+    }
+    if (kind) g *= 4.f;
+    dv[i] = g * (1.f - s) * s;
+}
+
+// torch.optim.SGD(momentum, nesterov=True, dampening 0, weight decay wd): buf = first ? g : mu buf + g; p -= lr (g + mu buf)
+__global__ void sgd_nesterov_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf, size_t n, float lr, float mu, float wd,
+                                    int first, float gscale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d = g[i] * gscale;
+    if (wd != 0.f) d += wd * p[i];
+    const float b = first ? d : mu * buf[i] + d;
+    buf[i] = b;
+    p[i] -= lr * (d + mu * b);
+}
+
+// copy a [N, C, HW] tensor into / out of a channel slice of a [N, ld, HW] tensor (torch.cat and its gradient)
+__global__ void slice_copy_kernel(const float *__restrict__ src, int src_ld, float *__restrict__ dst, int dst_ld, int C, int HW, size_t total, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = i / ((size_t)C * HW), rem = i - n * (size_t)C * HW;
+    const float v = src[n * (size_t)src_ld * HW + rem];
+    float *d = dst + n * (size_t)dst_ld * HW + rem;
+    *d = accumulate ? *d + v : v;
+}
+
+static int t_ws(pn_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->train_ws_bytes) {
+        if (ctx->train_ws) {
+            PN_HIP_CHECK(ctx, hipDeviceSynchronize());
+            (void)hipFree(ctx->train_ws);
+            ctx->train_ws = nullptr;
+            ctx->train_ws_bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        PN_HIP_CHECK(ctx, hipMalloc(&ctx->train_ws, want));
+        ctx->train_ws_bytes = want;
+    }
+    *out = ctx->train_ws;
+    return PN_OK;
+}
+
+static int t_slices(long total, int C) {       // slices per channel so that the reduction fills the chip
+    long s = (1024 + C - 1) / C;
+    const long cap = (total + 4095) / 4096;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+#define T_CTX_CHECK(name)                                                                                   \
+    if (!ctx) return PN_ERR_INVALID;                                                                        \
+    if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
+
+extern "C" {
+
+int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const float *bias_dev, float *y_dev, int N, int Cin, int H, int W,
+                      int Cout, int ks, int stride, int pad, int accumulate, void *hip_stream) {
+    T_CTX_CHECK("pn_conv2d_forward")
+    if (!x_dev || !w_dev || !y_dev || N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || stride < 1 || pad < 0 || (ks != 1 && ks != 3 && ks != 7))
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_forward: bad arguments (kernel sizes 1, 3, 7)");
+    TConv c;
+    c.x = x_dev; c.w = w_dev; c.bias = bias_dev; c.y = y_dev;
+    c.N = N; c.Cin = Cin; c.H = H; c.W = W; c.Cout = Cout; c.stride = stride; c.pad = pad; c.accumulate = accumulate;
+    c.Ho = (H + 2 * pad - ks) / stride + 1;
+    c.Wo = (W + 2 * pad - ks) / stride + 1;
+    c.Kdim = Cin * ks * ks;
+    const long P = (long)N * c.Ho * c.Wo;
+    if (c.Ho < 1 || c.Wo < 1 || P > 0x7fffffffL)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_forward: size out of range");
+    c.P = (int)P;
+    dim3 grid((unsigned)((P + 127) / 128), (unsigned)((Cout + 63) / 64)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (ks == 1) hipLaunchKernelGGL(tconv_fwd_kernel<1>, grid, block, 0, s, c);
+    else if (ks == 3) hipLaunchKernelGGL(tconv_fwd_kernel<3>, grid, block, 0, s, c);
+    else hipLaunchKernelGGL(tconv_fwd_kernel<7>, grid, block, 0, s, c);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float *dx_dev, int N, int Cin, int H, int W, int Cout, int ks, int pad,
+                    int accumulate, void *hip_stream) {
+    T_CTX_CHECK("pn_conv2d_dgrad")
+    if (!dy_dev || !w_dev || !dx_dev || (ks != 1 && ks != 3 && ks != 7) || pad > ks - 1)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_dgrad: bad arguments (stride 1 only)");
+    const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
+    const size_t wn = (size_t)Cout * Cin * ks * ks;
+    void *ws = nullptr;
+    int rc = t_ws(ctx, wn * sizeof(float), &ws);
+    if (rc != PN_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(wflip_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, ks);
+    // dX = conv(dY [N, Cout, Ho, Wo], Wt [Cin, Cout, ks, ks], padding ks - 1 - pad)
+    return pn_conv2d_forward(ctx, dy_dev, (const float *)ws, nullptr, dx_dev, N, Cout, Ho, Wo, Cin, ks, 1, ks - 1 - pad, accumulate, hip_stream);
+}
+
+int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float *dw_dev, float *dbias_dev, int N, int Cin, int H, int W, int Cout,
+                    int ks, int stride, int pad, void *hip_stream) {
+    T_CTX_CHECK("pn_conv2d_wgrad")
+    if (!x_dev || !dy_dev || !dw_dev || N < 1 || (ks != 1 && ks != 3 && ks != 7) || stride < 1)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_wgrad: bad arguments");
+    TConv c;
+    c.x = x_dev; c.w = nullptr; c.bias = nullptr; c.y = (float *)dy_dev;
+    c.N = N; c.Cin = Cin; c.H = H; c.W = W; c.Cout = Cout; c.stride = stride; c.pad = pad; c.accumulate = 0;
+    c.Ho = (H + 2 * pad - ks) / stride + 1;
+    c.Wo = (W + 2 * pad - ks) / stride + 1;
+    c.Kdim = Cin * ks * ks;
+    const long P = (long)N * c.Ho * c.Wo;
+    if (c.Ho < 1 || c.Wo < 1 || P > 0x7fffffffL) return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_wgrad: size out of range");
+    c.P = (int)P;
+    const int tiles = ((c.Kdim + 63) / 64) * ((Cout + 63) / 64);
+    long slices = (1024 + tiles - 1) / tiles;
+    const long cap = (P + 1023) / 1024;
+    if (slices > cap) slices = cap;
+    if (slices < 1) slices = 1;
+    long pps = (P + slices - 1) / slices;
+    pps = (pps + TW_RC - 1) / TW_RC * TW_RC;
+    slices = (P + pps - 1) / pps;
+    const size_t wn = (size_t)Cout * c.Kdim;
+    const int csl = t_slices(P, Cout);
+    void *ws = nullptr;
+    int rc = t_ws(ctx, wn * slices * sizeof(float) + 16 + (size_t)Cout * csl * 2 * sizeof(double), &ws);
+    if (rc != PN_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    dim3 grid((unsigned)((c.Kdim + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)slices), block(256);
+    if (ks == 1) hipLaunchKernelGGL(tconv_wgrad_kernel<1>, grid, block, 0, s, c, (float *)ws, (int)pps);
+    else if (ks == 3) hipLaunchKernelGGL(tconv_wgrad_kernel<3>, grid, block, 0, s, c, (float *)ws, (int)pps);
+    else hipLaunchKernelGGL(tconv_wgrad_kernel<7>, grid, block, 0, s, c, (float *)ws, (int)pps);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, (int)slices);
+    if (dbias_dev) {
+        double *part = (double *)((char *)ws + ((wn * slices * sizeof(float) + 15) & ~(size_t)15));
+        hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, 0, N, Cout,
+                           c.Ho * c.Wo, csl, part);
+        hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl, dbias_dev, nullptr, nullptr);
+    }
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev, const float *beta_dev, const float *res_dev, float *y_dev,
+                        float *save_mean_dev, float *save_invstd_dev, float *running_mean_dev, float *running_var_dev, float momentum, float eps,
+                        int act, int N, int C, int HW, void *hip_stream) {
+    T_CTX_CHECK("pn_bn_train_forward")
+    if (!x_dev || !gamma_dev || !beta_dev || !y_dev || !save_mean_dev || !save_invstd_dev || N < 1 || C < 1 || HW < 1 || (long)N * HW < 2)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_forward: bad arguments");
+    const long cnt = (long)N * HW;
+    const int sl = t_slices(cnt, C);
+    void *ws = nullptr;
+    int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double), &ws);
+    if (rc != PN_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, nullptr, nullptr, nullptr, 0, N, C, HW, sl, (double *)ws);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, (double)cnt, eps, momentum,
+                       save_mean_dev, save_invstd_dev, running_mean_dev, running_var_dev);
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev, save_invstd_dev,
+                       res_dev, act, C, HW, total, y_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, const float *out_dev, const float *gamma_dev, const float *save_mean_dev,
+                         const float *save_invstd_dev, int act, int N, int C, int HW, float *dx_dev, float *dgamma_dev, float *dbeta_dev,
+                         float *dres_dev, int dres_accumulate, void *hip_stream) {
+    T_CTX_CHECK("pn_bn_train_backward")
+    if (!x_dev || !dy_dev || !gamma_dev || !save_mean_dev || !save_invstd_dev || !dx_dev || !dgamma_dev || !dbeta_dev || (act != PN_ACT_NONE && !out_dev))
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: bad arguments");
+    const long cnt = (long)N * HW;
+    const int sl = t_slices(cnt, C);
+    void *ws = nullptr;
+    int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double), &ws);
+    if (rc != PN_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, dy_dev, out_dev, save_mean_dev, act, N, C, HW, sl, (double *)ws);
+    hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, dbeta_dev, dgamma_dev, save_invstd_dev);
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, save_mean_dev,
+                       save_invstd_dev, (const double *)ws, sl, act, C, HW, total, (double)cnt, dx_dev, dres_dev, dres_accumulate);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_avgpool3s2_forward(pn_ctx *ctx, const float *x_dev, float *y_dev, int planes, int H, int W, void *hip_stream) {
+    T_CTX_CHECK("pn_avgpool3s2_forward")
+    if (!x_dev || !y_dev || planes < 1 || H < 1 || W < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_avgpool3s2_forward: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)planes * Ho * Wo;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, x_dev, H, W, Ho, Wo, total, y_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_avgpool3s2_backward(pn_ctx *ctx, const float *dy_dev, float *dx_dev, int planes, int H, int W, void *hip_stream) {
+    T_CTX_CHECK("pn_avgpool3s2_backward")
+    if (!dy_dev || !dx_dev || planes < 1 || H < 1 || W < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_avgpool3s2_backward: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)planes * H * W;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, dy_dev, H, W, Ho, Wo, total, dx_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_head_forward(pn_ctx *ctx, const float *v_dev, const float *target_dev, const float *fg_dev, int kind, int N, int C, int HW, float *s_dev,
+                    float *out_dev, int out_ld, float *loss_dev, void *hip_stream) {
+    T_CTX_CHECK("pn_head_forward")
+    if (!v_dev || !target_dev || !s_dev || !out_dev || !loss_dev || out_ld < C || N < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_head_forward: bad arguments");
+    const size_t total = (size_t)N * C * HW;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    void *ws = nullptr;
+    int rc = t_ws(ctx, (size_t)nb * sizeof(double), &ws);
+    if (rc != PN_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(nb), dim3(256), 0, s, v_dev, target_dev, fg_dev, kind, C, HW, total, s_dev, out_dev, out_ld, (double *)ws);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, (const double *)ws, (int)nb, (double)total, loss_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_head_backward(pn_ctx *ctx, const float *s_dev, const float *target_dev, const float *fg_dev, const float *dextra_dev, int dextra_ld, int kind,
+                     int N, int C, int HW, float *dv_dev, void *hip_stream) {
+    T_CTX_CHECK("pn_head_backward")
+    if (!s_dev || !target_dev || !dv_dev || (dextra_dev && dextra_ld < C)) return pn_set_error(ctx, PN_ERR_INVALID, "pn_head_backward: bad arguments");
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, s_dev, target_dev, fg_dev, dextra_dev,
+                       dextra_ld, kind, C, HW, total, (float)(1.0 / (double)total), dv_dev);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_slice_copy(pn_ctx *ctx, const float *src_dev, int src_ld, float *dst_dev, int dst_ld, int N, int C, int HW, int accumulate, void *hip_stream) {
+    T_CTX_CHECK("pn_slice_copy")
+    if (!src_dev || !dst_dev || src_ld < C || dst_ld < C) return pn_set_error(ctx, PN_ERR_INVALID, "pn_slice_copy: bad arguments");
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(slice_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, src_dev, src_ld, dst_dev, dst_ld, C, HW,
+                       total, accumulate);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_sgd_nesterov(pn_ctx *ctx, float *param_dev, const float *grad_dev, float *momentum_buf_dev, size_t n, float lr, float momentum, float weight_decay,
+                    int first_step, float grad_scale, void *hip_stream) {
+    T_CTX_CHECK("pn_sgd_nesterov")
+    if (!param_dev || !grad_dev || !momentum_buf_dev) return pn_set_error(ctx, PN_ERR_INVALID, "pn_sgd_nesterov: bad arguments");
+    if (n == 0) return PN_OK;
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, param_dev, grad_dev, momentum_buf_dev, n,
+                       lr, momentum, weight_decay, first_step, grad_scale);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+}  // extern "C"

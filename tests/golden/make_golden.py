@@ -714,14 +714,81 @@ def golden_targets():
     print("F10: targets.npz:", len(out), "arrays; persons per composed item", [out["it%d_kp3d" % i].shape[0] for i in range(2)])
 
 
+def train_case_inputs(seed=21, B=3, H=96, W=128):
+    """Seeded batch + targets of the training goldens (also imported by the tests)."""
+    rng = np.random.default_rng(seed)
+    h, w = H // 8, W // 8
+    img = rng.normal(0, 1, (B, 1, H, W)).astype(np.float32)
+    heat = rng.uniform(0, 1, (B, 16, h, w)).astype(np.float32)
+    paf = rng.uniform(-1, 1, (B, 28, h, w)).astype(np.float32)
+    z = rng.uniform(-1.5, 1.5, (B, 15, h, w)).astype(np.float32)
+    fg = (rng.uniform(0, 1, (B, 15, h, w)) < 0.3).astype(np.float32)
+    return img, heat, paf, z, fg
+
+
+def sample_indices(name, numel, n=48):
+    """Which entries of a tensor the fixture keeps (seeded by the parameter name)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    return np.sort(rng.choice(numel, size=min(n, numel), replace=False))
+
+
+def golden_train():
+    """F11: the reference's OWN training step -- rtpose_light3d(...).train() forward, rtpose_light3d_loss_fgweight
+    (lib/network/losses.py:65-106), total_loss.backward(), torch.optim.SGD(lr=1, momentum=0.9, nesterov=True).step()
+    (train_rtpose_light3d_kdh3d_mpaug.py:160-180,313-316 (CR)) -- two consecutive steps on a seeded batch.  Kept per
+    parameter: gradient L2 norm, sum and 48 sampled entries; the same for the parameters after each step; BN running
+    statistics in full; the loss terms and the logged extrema."""
+    import torch
+    from popnet_amd import synth
+    from lib.network.rtpose_light3d import rtpose_light3d
+    from lib.network.losses import rtpose_light3d_loss_fgweight
+    torch.manual_seed(0)
+    model = rtpose_light3d(15, 14, 2, input_dim=1)
+    model.load_state_dict(np_sd(synth.fill_state_dict(model.state_dict(), seed=0)))
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1.0, momentum=0.9, weight_decay=0.0, nesterov=True)
+    names = ["l1_paf", "l1_heat", "l1_z", "l2_paf", "l2_heat", "l2_z"]
+    img, heat, paf, z, fg = [torch.from_numpy(a) for a in train_case_inputs()]
+    out = {}
+    for step in range(2):
+        _, saved = model(img)
+        total, log = rtpose_light3d_loss_fgweight(saved, heat, paf, z, fg, 2, names)
+        opt.zero_grad()
+        total.backward()
+        out["s%d_loss" % step] = np.float64(total.item())
+        out["s%d_terms" % step] = np.array([log[n] for n in names])
+        out["s%d_extrema" % step] = np.array([log[k] for k in ("max_ht", "min_ht", "max_paf", "min_paf", "max_z", "min_z")])
+        for name, p in model.named_parameters():
+            if p.grad is None:          # model0.layer3.* does not exist in rtpose; every parameter takes part
+                raise RuntimeError(name)
+            g = p.grad.detach().numpy().ravel()
+            idx = sample_indices(name, g.size)
+            out["s%d_g_norm/%s" % (step, name)] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            out["s%d_g_sum/%s" % (step, name)] = np.float64(g.astype(np.float64).sum())
+            out["s%d_g_samp/%s" % (step, name)] = g[idx].copy()
+        opt.step()
+        for name, p in model.named_parameters():
+            v = p.detach().numpy().ravel()
+            out["s%d_p_samp/%s" % (step, name)] = v[sample_indices(name, v.size)].copy()
+            out["s%d_p_norm/%s" % (step, name)] = np.float64(np.sqrt((v.astype(np.float64) ** 2).sum()))
+        for name, b in model.named_buffers():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                out["s%d_stat/%s" % (step, name)] = b.detach().numpy().copy()
+    out["saved_sizes"] = np.array([list(s.shape) for s in saved])
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **out)
+    print("train_step.npz: loss", out["s0_loss"], "->", out["s1_loss"])
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate golden vectors"
     install_shims()
     import popnet_amd  # noqa: F401
-    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo", "targets"]
+    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo", "targets", "train"]
     fns = {"keys": golden_state_dicts, "forward": golden_forward, "parse": golden_parse, "yolo": golden_yolo,
            "pafprocess": golden_pafprocess, "script": golden_script,
            "script_yolo": golden_script_yolo, "metrics": golden_metrics, "script_metrics": golden_script_metrics,
-           "script_metrics_yolo": lambda: golden_script_metrics("yolo"), "targets": golden_targets}
+           "script_metrics_yolo": lambda: golden_script_metrics("yolo"), "targets": golden_targets, "train": golden_train}
     for w in which:
         fns[w]()

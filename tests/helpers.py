@@ -103,3 +103,21 @@ def humans_to_array(humans):
 
 
 PAFPROCESS_CASES = [(40, 1), (41, 2), (42, 4), (43, 0), (44, 6)]
+
+
+# ---- training goldens (must mirror tests/golden/make_golden.py::train_case_inputs / sample_indices) ----
+def train_case_inputs(seed=21, B=3, H=96, W=128):
+    rng = np.random.default_rng(seed)
+    h, w = H // 8, W // 8
+    img = rng.normal(0, 1, (B, 1, H, W)).astype(np.float32)
+    heat = rng.uniform(0, 1, (B, 16, h, w)).astype(np.float32)
+    paf = rng.uniform(-1, 1, (B, 28, h, w)).astype(np.float32)
+    z = rng.uniform(-1.5, 1.5, (B, 15, h, w)).astype(np.float32)
+    fg = (rng.uniform(0, 1, (B, 15, h, w)) < 0.3).astype(np.float32)
+    return img, heat, paf, z, fg
+
+
+def sample_indices(name, numel, n=48):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    return np.sort(rng.choice(numel, size=min(n, numel), replace=False))
