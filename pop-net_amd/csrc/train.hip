@@ -52,24 +52,32 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
         iy0 = oy * c.stride - c.pad;
         ix0 = ox * c.stride - c.pad;
     }
+    // every load is unconditional (an out-of-range element reads index 0; it is zeroed when the value goes to LDS, one chunk
+    // later -- a select right after the load would put an s_waitcnt vmcnt(0) in front of the MFMAs the load is meant to
+    // overlap with, and a conditional load becomes a branch of its own: 73 of them in the first version of this loop)
     const float *xb = c.x + (size_t)bn * c.Cin * c.H * c.W;
     const bool a_ok = co0 + a_co < c.Cout;
-    const float *wa = c.w + (size_t)(co0 + a_co) * c.Kdim;
+    const float *wa = c.w + (a_ok ? (size_t)(co0 + a_co) * c.Kdim : 0);
 
     float ra[4], rb[8];
+    unsigned okm = 0;          // bit j: rb[j] valid, bit 8 + j: ra[j] valid
     auto load = [&](int k0) {
+        okm = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = k0 + a_k0 + j;
-            ra[j] = (a_ok && k < c.Kdim) ? wa[k] : 0.f;
+            const int ok = (int)(a_ok & (k < c.Kdim));
+            ra[j] = wa[k & -ok];
+            okm |= (unsigned)ok << (8 + j);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + b_k0 + 2 * j;
             const int ci = k / (KS * KS), rr = k - ci * (KS * KS), ky = rr / KS, kx = rr - ky * KS;
             const int iy = iy0 + ky, ix = ix0 + kx;
-            const bool ok = bp_ok && k < c.Kdim && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W;
-            rb[j] = ok ? xb[((size_t)ci * c.H + iy) * c.W + ix] : 0.f;
+            const int ok = (int)(bp_ok & (k < c.Kdim) & (iy >= 0) & (iy < c.H) & (ix >= 0) & (ix < c.W));
+            rb[j] = xb[((ci * c.H + iy) * c.W + ix) & -ok];
+            okm |= (unsigned)ok << j;
         }
     };
     t_f32x4 acc[4][2];
@@ -82,9 +90,9 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
     for (int k0 = 0; k0 < c.Kdim; k0 += TC_KC) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) As[a_k0 + j][a_co] = ra[j];
+        for (int j = 0; j < 4; ++j) As[a_k0 + j][a_co] = (okm >> (8 + j)) & 1u ? ra[j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Bs[b_k0 + 2 * j][b_pn] = rb[j];
+        for (int j = 0; j < 8; ++j) Bs[b_k0 + 2 * j][b_pn] = (okm >> j) & 1u ? rb[j] : 0.f;
         __syncthreads();
         if (k0 + TC_KC < c.Kdim) load(k0 + TC_KC);
 #pragma unroll
@@ -100,25 +108,201 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
         }
     }
-    // epilogue: lane holds couts 16m + 4q + i of pixel 32 wave + 16 n + r
+    // epilogue: lane holds couts 16m + 4q + i of pixel 32 wave + 16 n + r; the accumulate form first gathers all old values
+    // (32 independent loads in flight), then adds and stores
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int p = p0 + 32 * wave + 16 * n + r;
-        if (p >= c.P) continue;
-        const int img = p / HoWo, rem = p - img * HoWo;
+        const int pok = (int)(p < c.P);
+        const int pc = p & -pok;
+        const int img = pc / HoWo, rem = pc - img * HoWo;
         float *yb = c.y + (size_t)img * c.Cout * HoWo + rem;
+        float old[16];
+        if (c.accumulate) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + 16 * m + 4 * q + i;
+                    old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
+                }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int co = co0 + 16 * m + 4 * q + i;
-                if (co >= c.Cout) continue;
                 float v = acc[m][n][i];
-                if (c.bias) v += c.bias[co];
-                float *o = yb + (size_t)co * HoWo;
-                *o = c.accumulate ? *o + v : v;
+                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                if (c.accumulate) v += old[4 * m + i];
+                if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
             }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolutions (95 % of the step's FLOPs), second generation.  PMC on the gather kernel above: the texture
+// addresser is as busy per CU as the matrix pipe per SIMD (TA/MFMA 1.01, MfmaUtil 28 %) -- every input element is fetched
+// nine times, once per tap, four bytes per lane.  Here a block stages the HALO TILE of 16 input channels once (rows of the
+// image, coalesced) plus the 9 x 16 x 64 weight slice (pre-transposed to [tap][ci][cout] by wpack_kernel, coalesced along
+// cout) and runs 288 MFMAs per wave between two barriers; the nine taps are LDS address offsets.  Output tile = R rows x TW
+// columns of one image, R * TW <= 128 (28-wide maps: 4 x 28, 56: 2 x 56, 112: 1 x 112).  Two blocks per CU overlap one
+// block's staging with the other's MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TTile {
+    int TW, R, tiles_x, tiles_y;   // output tile, tiles per image
+    int HC, HR;                    // halo columns / rows = TW + 2, R + 2
+    int CHP;                       // LDS floats per halo channel (HR * HC rounded up to = 16 mod 64: forward, = 4 mod 64: wgrad)
+    int NI;                        // ceil(HR * HC / 256)
+};
+#define TT_AP 80
+#define TT_MAXNI 2
+
+// wp[tap][ci][co] = flip ? W[co_w = ci][ci_w = co][8 - tap] : W[co][ci][tap]   (flip: the data gradient's transposed, rotated weights)
+__global__ void wpack3_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * Cin * Cout) return;
+    const int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cout * Cin);
+    wp[i] = flip ? w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : w[((size_t)co * Cin + ci) * 9 + tap];
+}
+
+__global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, const float *__restrict__ wp) {
+    extern __shared__ float t_smem[];
+    float *As = t_smem;                       // [9 * 16][TT_AP]   weights  (tap, channel) x cout
+    float *Hs = t_smem + 144 * TT_AP;         // [16][CHP]         halo tile of 16 input channels
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int b = blockIdx.x, tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
+    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = blockIdx.y * 64;
+    const int HW = c.H * c.W, HoWo = c.Ho * c.Wo;
+    // this lane's two pixel slots (MFMA columns)
+    int hb[2], opix[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int sl = 32 * wave + 16 * n + r;
+        const int ry = sl / g.TW, rx = sl - ry * g.TW;
+        const bool ok = ry < g.R && y0 + ry < c.Ho && x0 + rx < c.Wo;
+        hb[n] = ok ? ry * g.HC + rx : 0;
+        opix[n] = ok ? (y0 + ry) * c.Wo + x0 + rx : -1;
+    }
+    // halo elements this thread stages for every channel: offset inside the image plane (or -1 = zero padding)
+    int hoff[TT_MAXNI], hdst[TT_MAXNI];
+#pragma unroll
+    for (int i = 0; i < TT_MAXNI; ++i) {
+        const int e = t + 256 * i;
+        const int hy = e / g.HC, hx = e - hy * g.HC;
+        const int iy = y0 - c.pad + hy, ix = x0 - c.pad + hx;
+        const bool in = e < g.HR * g.HC;
+        hdst[i] = in ? e : -1;
+        hoff[i] = (in && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W) ? iy * c.W + ix : -1;
+    }
+    const float *xb = c.x + (size_t)img * c.Cin * HW;
+    const int a_co = t & 63, a_r0 = t >> 6;
+    const bool a_ok = co0 + a_co < c.Cout;
+    const float *wa = wp + (a_ok ? co0 + a_co : 0);
+
+    t_f32x4 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < c.Cin; c0 += 16) {
+        float rh[16 * TT_MAXNI];
+        float rw[36];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int cok = (int)(c0 + kk < c.Cin);
+#pragma unroll
+            for (int i = 0; i < TT_MAXNI; ++i) {
+                const int ok = cok & (int)(hoff[i] >= 0);
+                rh[kk * TT_MAXNI + i] = xb[((c0 + kk) * HW + hoff[i]) & -ok];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 36; ++j) {            // row = tap * 16 + kk
+            const int row = a_r0 + 4 * j, tap = row >> 4, kk = row & 15;
+            const int ok = (int)(c0 + kk < c.Cin);
+            rw[j] = wa[((tap * c.Cin + c0 + kk) * c.Cout) & -ok];
+        }
+        __syncthreads();                          // the previous chunk's MFMAs have read their fragments
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int i = 0; i < TT_MAXNI; ++i)
+                if (hdst[i] >= 0) Hs[kk * g.CHP + hdst[i]] = (c0 + kk < c.Cin && hoff[i] >= 0) ? rh[kk * TT_MAXNI + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 36; ++j) {
+            const int row = a_r0 + 4 * j;
+            As[row * TT_AP + a_co] = (a_ok && c0 + (row & 15) < c.Cin) ? rw[j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * g.HC + (tap % 3);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float a[4], bb[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = As[(tap * 16 + 4 * ks + q) * TT_AP + 16 * m + r];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bb[n] = Hs[(4 * ks + q) * g.CHP + hb[n] + toff];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bb[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int pok = (int)(opix[n] >= 0);
+        float *yb = c.y + (size_t)img * c.Cout * HoWo + (opix[n] & -pok);
+        float old[16];
+        if (c.accumulate) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + 16 * m + 4 * q + i;
+                    old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * m + 4 * q + i;
+                float v = acc[m][n][i];
+                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                if (c.accumulate) v += old[4 * m + i];
+                if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
+            }
+    }
+}
+
+static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 KB of dynamic LDS: lift the 64 KB default once per process
+    static bool done = false;
+    if (!done) {
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done = true;
+    }
+    return PN_OK;
+}
+
+static bool t_tile_geometry(int Ho, int Wo, int mod, TTile *g) {
+    g->TW = Wo < 128 ? Wo : 128;
+    g->R = 128 / g->TW;
+    if (g->R > Ho) g->R = Ho;
+    if (g->R < 1) g->R = 1;
+    g->tiles_x = (Wo + g->TW - 1) / g->TW;
+    g->tiles_y = (Ho + g->R - 1) / g->R;
+    g->HC = g->TW + 2;
+    g->HR = g->R + 2;
+    const int n = g->HR * g->HC;
+    g->NI = (n + 255) / 256;
+    g->CHP = (n + 63) / 64 * 64 + mod;        // = mod (mod 64)
+    if (g->CHP - 64 >= n) g->CHP -= 64;
+    return g->NI <= TT_MAXNI;
 }
 
 // Weights for the data gradient: Wt[ci][(co, ky', kx')] = W[co][ci][KS-1-ky'][KS-1-kx']
@@ -161,7 +345,9 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
     }
     const int pbeg = slice * pix_per_slice, pend = min(pbeg + pix_per_slice, c.P);
     float ra[8], rb[8];
+    unsigned okm = 0;          // bit j: rb[j] valid, bit 8 + j: ra[j] valid (the select happens when the values go to LDS)
     auto load = [&](int pc) {
+        okm = 0;
         const int p = pc + pl;
         const bool ok = p < pend;
         int img = 0, rem = 0, oy = 0, ox = 0;
@@ -175,12 +361,14 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
         const float *xb = c.x + (size_t)img * c.Cin * c.H * c.W;
         const int iy0 = oy * c.stride - c.pad, ix0 = ox * c.stride - c.pad;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 8; ++j) {            // unconditional loads + selects (see tconv_fwd_kernel)
             const int co = co0 + g + 8 * j;
-            ra[j] = (ok && co < c.Cout) ? dyb[(size_t)co * HoWo] : 0.f;
+            const int oka = (int)(ok & (co < c.Cout));
+            ra[j] = dyb[(co * HoWo) & -oka];
             const int iy = iy0 + kky[j], ix = ix0 + kkx[j];
-            const bool okb = ok && kci[j] >= 0 && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W;
-            rb[j] = okb ? xb[((size_t)kci[j] * c.H + iy) * c.W + ix] : 0.f;
+            const int okb = (int)(ok & (kci[j] >= 0) & (iy >= 0) & (iy < c.H) & (ix >= 0) & (ix < c.W));
+            rb[j] = xb[((kci[j] * c.H + iy) * c.W + ix) & -okb];
+            okm |= ((unsigned)oka << (8 + j)) | ((unsigned)okb << j);
         }
     };
     t_f32x4 acc[4];
@@ -191,8 +379,8 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            As[pl][g + 8 * j] = ra[j];
-            Bs[pl][g + 8 * j] = rb[j];
+            As[pl][g + 8 * j] = (okm >> (8 + j)) & 1u ? ra[j] : 0.f;
+            Bs[pl][g + 8 * j] = (okm >> j) & 1u ? rb[j] : 0.f;
         }
         __syncthreads();
         if (pc + TW_RC < pend) load(pc + TW_RC);
@@ -300,12 +488,13 @@ __global__ void sums_finish_kernel(const double *__restrict__ partial, int C, in
     if (out1) out1[ch] = (float)(invstd ? ss * (double)invstd[ch] : ss);   // d gamma = sum g (x - mean) * invstd
 }
 
-__global__ void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                                 const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ res, int act,
-                                int C, int HW, size_t total, float *__restrict__ y) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ch = (int)((i / HW) % C);
+                                int C, int HW, float *__restrict__ y) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const int ch = blockIdx.y % C;
+    const size_t i = (size_t)blockIdx.y * HW + p;
     float v = (x[i] - mean[ch]) * invstd[ch] * gamma[ch] + beta[ch];
     if (res) v += res[i];
     if (act == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -314,20 +503,20 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, const float *__rest
 }
 
 // dx = gamma * invstd * (g - sum_g / n - (x - mean) * invstd^2 * sum_gx / n);  dres (+)= g   (identity path of a BasicBlock)
-__global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
+// grid (ceil(HW / 256), N * C): the channel is uniform per block, no division per element
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
                                     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                    const double *__restrict__ partial, int slices, int act, int C, int HW, size_t total, double count,
+                                    const float *__restrict__ sum_g, const float *__restrict__ sum_gx, int act, int C, int HW, float inv_count,
                                     float *__restrict__ dx, float *__restrict__ dres, int dres_accumulate) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ch = (int)((i / HW) % C);
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const int ch = blockIdx.y % C;
+    const size_t i = (size_t)blockIdx.y * HW + p;
     float g = dy[i];
     if (act == PN_ACT_RELU) g = out[i] > 0.f ? g : 0.f;
     else if (act == PN_ACT_LEAKY) g = out[i] > 0.f ? g : g * 0.1f;
     const float is = invstd[ch];
-    const float mg = (float)(s / count), k2 = (float)(ss / count) * is * is;
+    const float mg = sum_g[ch] * inv_count, k2 = sum_gx[ch] * inv_count * is * is;
     dx[i] = (g - mg - (x[i] - mean[ch]) * k2) * is * gamma[ch];
     if (dres) dres[i] = dres_accumulate ? dres[i] + g : g;
 }
@@ -383,11 +572,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-__global__ void loss_finish_kernel(const double *__restrict__ partial, int nblocks, double numel, float *__restrict__ loss) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ __launch_bounds__(256) void loss_finish_kernel(const double *__restrict__ partial, int nblocks, double numel, float *__restrict__ loss) {
+    __shared__ double sh[4];
     double s = 0.0;
-    for (int i = 0; i < nblocks; ++i) s += partial[i];
-    *loss = (float)(s / numel);
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    const double r = t_block_sum(s, sh);
+    if (threadIdx.x == 0) *loss = (float)(r / numel);
 }
 
 // dv = (2 w (out - t) / numel + dextra) * (kind ? 4 : 1) * s (1 - s)
@@ -475,8 +665,22 @@ int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const
     if (c.Ho < 1 || c.Wo < 1 || P > 0x7fffffffL)
         return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_forward: size out of range");
     c.P = (int)P;
-    dim3 grid((unsigned)((P + 127) / 128), (unsigned)((Cout + 63) / 64)), block(256);
     hipStream_t s = (hipStream_t)hip_stream;
+    TTile g;
+    if (ks == 3 && stride == 1 && pad <= 2 && Cin >= 16 && t_tile_geometry(c.Ho, c.Wo, 16, &g)) {
+        // second-generation 3x3 kernel: weights to [tap][ci][cout] in the scratch, then halo tiles
+        const size_t wn = (size_t)Cout * Cin * 9;
+        void *ws = nullptr;
+        int rc = t_ws(ctx, wn * sizeof(float), &ws);
+        if (rc != PN_OK) return rc;
+        if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
+        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, 0);
+        const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
+        hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
+        PN_HIP_CHECK(ctx, hipGetLastError());
+        return PN_OK;
+    }
+    dim3 grid((unsigned)((P + 127) / 128), (unsigned)((Cout + 63) / 64)), block(256);
     if (ks == 1) hipLaunchKernelGGL(tconv_fwd_kernel<1>, grid, block, 0, s, c);
     else if (ks == 3) hipLaunchKernelGGL(tconv_fwd_kernel<3>, grid, block, 0, s, c);
     else hipLaunchKernelGGL(tconv_fwd_kernel<7>, grid, block, 0, s, c);
@@ -495,6 +699,20 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
     int rc = t_ws(ctx, wn * sizeof(float), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
+    TTile g;
+    if (ks == 3 && Cout >= 16 && t_tile_geometry(H, W, 16, &g)) {
+        // dX = conv(dY, rotated transposed weights, padding 2 - pad) on the halo-tile kernel: the packing IS the rotation
+        TConv c;
+        c.x = dy_dev; c.w = nullptr; c.bias = nullptr; c.y = dx_dev;
+        c.N = N; c.Cin = Cout; c.H = Ho; c.W = Wo; c.Cout = Cin; c.stride = 1; c.pad = 2 - pad; c.accumulate = accumulate;
+        c.Ho = H; c.Wo = W; c.Kdim = Cout * 9; c.P = N * H * W;
+        if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
+        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cin, Cout, 1);
+        const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
+        hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
+        PN_HIP_CHECK(ctx, hipGetLastError());
+        return PN_OK;
+    }
     hipLaunchKernelGGL(wflip_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, ks);
     // dX = conv(dY [N, Cout, Ho, Wo], Wt [Cin, Cout, ks, ks], padding ks - 1 - pad)
     return pn_conv2d_forward(ctx, dy_dev, (const float *)ws, nullptr, dx_dev, N, Cout, Ho, Wo, Cin, ks, 1, ks - 1 - pad, accumulate, hip_stream);
@@ -558,9 +776,9 @@ int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev,
     hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, nullptr, nullptr, nullptr, 0, N, C, HW, sl, (double *)ws);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, (double)cnt, eps, momentum,
                        save_mean_dev, save_invstd_dev, running_mean_dev, running_var_dev);
-    const size_t total = (size_t)N * C * HW;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev, save_invstd_dev,
-                       res_dev, act, C, HW, total, y_dev);
+    if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_forward: N * C out of range");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev, save_invstd_dev,
+                       res_dev, act, C, HW, y_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -574,14 +792,17 @@ int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, c
     const long cnt = (long)N * HW;
     const int sl = t_slices(cnt, C);
     void *ws = nullptr;
-    int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double), &ws);
+    int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double) + (size_t)C * sizeof(float), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, dy_dev, out_dev, save_mean_dev, act, N, C, HW, sl, (double *)ws);
-    hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, dbeta_dev, dgamma_dev, save_invstd_dev);
-    const size_t total = (size_t)N * C * HW;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, save_mean_dev,
-                       save_invstd_dev, (const double *)ws, sl, act, C, HW, total, (double)cnt, dx_dev, dres_dev, dres_accumulate);
+    // d beta = sum g, sum g (x - mean) (raw, into the scratch) and d gamma = that * invstd
+    float *sgx = (float *)((char *)ws + (size_t)C * sl * 2 * sizeof(double));
+    hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, dbeta_dev, sgx, nullptr);
+    hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, nullptr, dgamma_dev, save_invstd_dev);
+    if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: N * C out of range");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, save_mean_dev,
+                       save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -617,7 +838,7 @@ int pn_head_forward(pn_ctx *ctx, const float *v_dev, const float *target_dev, co
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(nb), dim3(256), 0, s, v_dev, target_dev, fg_dev, kind, C, HW, total, s_dev, out_dev, out_ld, (double *)ws);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, (const double *)ws, (int)nb, (double)total, loss_dev);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, (const double *)ws, (int)nb, (double)total, loss_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }

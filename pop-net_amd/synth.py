@@ -171,3 +171,15 @@ class SynthSweep:
             if drop_last and len(chunk) < batch_size:
                 return
             yield chunk, np.stack([self.load(i) for i in chunk])
+
+
+def init_like_state_dict(seed=0):
+    """The state a training run starts from: the module's own constructor (conv weights N(0, 0.01) as
+    rtpose_light3d._initialize_weights_norm does, third_party_methods/lib/network/rtpose_light3d.py:358-362; BatchNorm 1 / 0)."""
+    import torch
+    from .network.rtpose_light3d import rtpose_light3d
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    sd = {k: v.detach().clone() for k, v in rtpose_light3d(15, 14, 2, input_dim=1).state_dict().items()}
+    torch.random.set_rng_state(g)
+    return sd

@@ -60,6 +60,12 @@ class TrainEngine:
         self._bufs = {}        # name -> tensor, reused across steps while the shape stays
         self.loss_terms = torch.zeros(6, dtype=torch.float32, device=self.device)
 
+    @classmethod
+    def from_module(cls, module, **kw):
+        """From a popnet_amd.network.rtpose_light3d.rtpose_light3d (or the reference's own module): its state_dict is copied;
+        module.load_state_dict(engine.state_dict()) hands the trained weights back to the inference path."""
+        return cls(module.state_dict(), **kw)
+
     # ---- plumbing ----
     def _s(self):
         return _lib.current_stream_ptr(self.device)
