@@ -129,6 +129,101 @@ def precision_modes_leg(dev, steps=30):
     return out
 
 
+def synth_training_batch(dev, B, seed=0, persons=2):
+    """A training batch the way the reference's dataset builds one (datasets_kdh3d_rtpose_mpaug.py:223-286 (CR)), on the GPU:
+    `persons` single-person source frames per item composited over a background, resized, and the heat / PAF / z / fg targets
+    rasterised from the planted skeletons (popnet_amd.targets.mpaug_batch).  Returns (batch tuple, seconds it took)."""
+    from popnet_amd import synth, targets
+    rng = np.random.default_rng(seed)
+    H, W = 640, 480
+    fd = torch.from_numpy(np.clip(rng.normal(2.5, 0.3, (B, persons, H, W)), 0.3, 5.9).astype(np.float16)).to(dev)
+    fm = torch.zeros((B, persons, H, W), dtype=torch.uint8, device=dev)
+    k2 = np.zeros((B, persons, 15, 2), dtype=np.float32)
+    k3 = np.zeros((B, persons, 15, 3))
+    for b in range(B):
+        j, d = synth.planted_persons(rng, persons, size=224)
+        k2[b] = j * np.array([W / 224.0, H / 224.0])               # annotations live in ORIGINAL pixel coordinates
+        k3[b, :, :, 2] = d[:, None]
+        for p in range(persons):
+            x0, y0 = np.maximum(k2[b, p].min(0).astype(int) - 10, 0)
+            x1, y1 = k2[b, p].max(0).astype(int) + 10
+            fm[b, p, y0:y1, x0:x1] = 1
+    bg = torch.from_numpy(np.clip(rng.normal(4.5, 0.3, (B, H, W)), 0, 6).astype(np.float16)).to(dev)
+    n_src = torch.full((B,), persons, dtype=torch.int32, device=dev)
+    npers = torch.full((B,), persons, dtype=torch.int32, device=dev)
+    k2d, k3d = torch.from_numpy(k2).to(dev), torch.from_numpy(k3).to(dev)
+    targets.mpaug_batch(fd, fm, n_src, bg, k2d, k3d, npers)           # warm
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x, heat, paf, z, fg = targets.mpaug_batch(fd, fm, n_src, bg, k2d, k3d, npers)
+    torch.cuda.synchronize()
+    return (x.contiguous(), heat, paf, z, fg), time.perf_counter() - t0
+
+
+def train_step_cpu(batch, threads=32):
+    """The oracle's training step (torch fp32 CPU autograd, oracle/train.py -- the checker, timed here as the CPU baseline of
+    the training workload only) on the same batch and initial state, one warm-up + one timed step."""
+    from oracle import train as otrain
+    from popnet_amd import synth
+    sd = synth.init_like_state_dict(seed=3)
+    cpu = [b.cpu() for b in batch]
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        otrain.train_step(sd, *cpu, lr=0.05)
+        t0 = time.perf_counter()
+        otrain.train_step(sd, *cpu, lr=0.05)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(old)
+    return {"ms_per_step": round(dt * 1e3, 1), "frames_per_s": round(len(cpu[0]) / dt, 2), "cores": threads, "kind": "port"}
+
+
+def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=False):
+    """BASELINE configs[4]: one training step of rtpose_light3d (train-mode forward, rtpose_light3d_loss_fgweight, backward,
+    Nesterov SGD; popnet_amd.train.TrainEngine, fp32, every kernel hand-written HIP) on BATCH frames of 224 x 224 per rank from the
+    reference's initial state, targets built on the GPU; with world > 1 the flat 22 MB gradient is all-reduced every step."""
+    from popnet_amd import synth
+    from popnet_amd.train import TrainEngine
+    batch, t_targets = synth_training_batch(dev, BATCH)
+    eng = TrainEngine(synth.init_like_state_dict(seed=3), device=dev, lr=lr, world_size=world, process_group=group)
+    first = None
+    for k in range(warmup):
+        t = eng.step(*batch)
+        if first is None:
+            first = float(t.sum())
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(group=group)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t = eng.step(*batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flops = 3 * 13.343e9 * BATCH                                     # forward + data gradient + weight gradient, SURVEY 8d's per-frame figure
+    extra = {"cpu_baseline": train_step_cpu(batch)} if cpu else {}
+    return {**extra, "ms_per_step": round(dt * 1e3, 3), "frames_per_s_per_gpu": round(BATCH / dt, 1), "tflops": round(flops / dt / 1e12, 1), "dtype": "f32",
+            "peak_tflops_f32_mfma": 157.0, "batch_per_gpu": BATCH, "input": "224x224", "parameters": int(eng.flat_p.numel()),
+            "loss_first_step": round(first, 5), "loss_last_step": round(float(t.sum()), 5), "targets_on_gpu_ms_per_batch": round(t_targets * 1e3, 3),
+            "what": "TrainEngine.step: train-mode forward (batch-statistics BatchNorm), fg-weighted loss, backward (MFMA dgrad / wgrad), Nesterov SGD; %s"
+                    % ("one all-reduce of the flat gradient per step over %d ranks" % world if world > 1 else "single GPU")}
+
+
+def train_workload(args, dev, world, rank, dist):
+    """`--workload train`: the training step as the timed workload (weak scaling: BATCH frames per rank per step)."""
+    leg = train_step_leg(dev, steps=args.steps if args.steps < 200 else 20, warmup=max(2, min(args.warmup, 5)), world=world, group=None)
+    ms = torch.tensor([leg["ms_per_step"]], device=dev)
+    if world > 1:
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        m = float(ms)
+        print(json.dumps({"metric": "training frames/sec (rtpose_light3d_kdh3d_mpaug step, 224x224)", "value": round(world * BATCH / (m / 1e3), 1), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps if args.steps < 200 else 20, "warmup": max(2, min(args.warmup, 5)), "ms_per_step": round(m, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[4]: training step, batch %d per GPU, data parallel" % BATCH}, "train_step": leg}))
+
+
 def launcher_dry_run(args):
     """CPU check of the self-launch path: every rank joins a gloo group, rank 0 prints one JSON line."""
     import torch.distributed as dist
@@ -160,6 +255,7 @@ def main():
     ap.add_argument("--pool", type=int, default=6, help="distinct input batches per slot (pipeline x pool x 19.7 MB should exceed the 256 MB Infinity Cache)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region per input mode; the median is reported")
     ap.add_argument("--launcher-dry-run", action="store_true", help="CPU check of the --gpus N self-launch (gloo, no GPU work)")
+    ap.add_argument("--workload", default="infer", choices=["infer", "train"], help="infer = the headline path (BASELINE configs[1]); train = the training step (configs[4])")
     args = ap.parse_args()
 
     from popnet_amd import launch                                   # touches no GPU
@@ -181,6 +277,11 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import popnet_amd  # noqa: F401
+    if args.workload == "train":
+        train_workload(args, dev, world, rank, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from popnet_amd import _lib, synth
     from popnet_amd.pipeline import PoseEngine, StreamingEngine, YoloEngine
     Engine = PoseEngine if args.net == "rtpose" else YoloEngine
@@ -379,6 +480,7 @@ def main():
         if world == 1 and args.net == "rtpose" and not args.no_extras:
             out["mpaug_parse"] = mpaug_parse_leg(engine)
             out["precision_modes"] = precision_modes_leg(dev)
+            out["train_step"] = train_step_leg(dev, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline and args.net == "rtpose":
             out["cpu_baseline"] = cpu_baseline(engine, depth_host)
         print(json.dumps(out))

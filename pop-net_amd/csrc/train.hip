@@ -280,10 +280,98 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
     }
 }
 
+// Weight gradient of the 3x3 stride-1 convolutions on the same tiles: a block owns 64 couts x (16 input channels x 9 taps) and
+// walks a slice of the output tiles; per tile it stages dY [128 pixel slots][64 couts] and the halo tile of its 16 input
+// channels, then 32 pixel groups x 9 taps = 288 MFMAs per wave (A = dY: row = cout, k = pixel; B = X: k = pixel, column =
+// channel, one 16-column MFMA tile per tap, the tap again an LDS address offset).  Partials per slice, reduced in order.
+#define TT_YP 81      // = 17 (mod 64): conflict-free pixel-major writes, near conflict-free (q * 17 + r) MFMA operand reads
+#define TT_HP 17      // halo tile of the weight gradient is PIXEL-major: [halo pixel][16 channels + 1]
+__global__ __launch_bounds__(256, 2) void tconv3_wgrad_tile_kernel(TConv c, TTile g, float *__restrict__ partial, int tiles_per_slice, int ntiles) {
+    extern __shared__ float t_smem[];
+    float *Ys = t_smem;                         // [128][TT_YP]   dY tile, pixel-major
+    float *Hs = t_smem + 128 * TT_YP;           // [HR * HC][TT_HP]  halo tile of this block's 16 input channels, pixel-major
+    int *hbt = (int *)(Hs + g.HR * g.HC * TT_HP);   // [128]       pixel slot -> halo pixel of its top-left tap
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int c0 = blockIdx.x * 16, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    const int HW = c.H * c.W, HoWo = c.Ho * c.Wo;
+    // per-thread constants of the staging: the dY slot and the halo elements (same for every tile up to the tile origin)
+    const int sl = t & 127, ry = sl / g.TW, rx = sl - ry * g.TW, y_c0 = t >> 7;
+    int hy[TT_MAXNI], hx[TT_MAXNI], hdst[TT_MAXNI];
+#pragma unroll
+    for (int i = 0; i < TT_MAXNI; ++i) {
+        const int e = t + 256 * i;
+        hy[i] = e / g.HC;
+        hx[i] = e - hy[i] * g.HC;
+        hdst[i] = e < g.HR * g.HC ? e : -1;
+    }
+    t_f32x4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tbeg = slice * tiles_per_slice, tend = min(tbeg + tiles_per_slice, ntiles);
+    for (int tile = tbeg; tile < tend; ++tile) {
+        const int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, img = tile / (g.tiles_x * g.tiles_y);
+        const int y0 = ty * g.R, x0 = tx * g.TW;
+        const bool sok = ry < g.R && y0 + ry < c.Ho && x0 + rx < c.Wo;
+        const float *dyb = c.y + (size_t)img * c.Cout * HoWo + (sok ? (y0 + ry) * c.Wo + x0 + rx : 0);
+        const float *xb = c.x + (size_t)img * c.Cin * HW;
+        float rd[32], rh[16 * TT_MAXNI];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int co = co0 + y_c0 + 2 * j;
+            rd[j] = dyb[(co * HoWo) & -(int)(sok & (co < c.Cout))];
+        }
+        int hoff[TT_MAXNI];
+#pragma unroll
+        for (int i = 0; i < TT_MAXNI; ++i) {
+            const int iy = y0 - c.pad + hy[i], ix = x0 - c.pad + hx[i];
+            hoff[i] = (hdst[i] >= 0 && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W) ? iy * c.W + ix : -1;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int i = 0; i < TT_MAXNI; ++i) {
+                const int ok = (int)(c0 + kk < c.Cin) & (int)(hoff[i] >= 0);
+                rh[kk * TT_MAXNI + i] = xb[((c0 + kk) * HW + hoff[i]) & -ok];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int co = co0 + y_c0 + 2 * j;
+            Ys[sl * TT_YP + y_c0 + 2 * j] = (sok && co < c.Cout) ? rd[j] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int i = 0; i < TT_MAXNI; ++i)
+                if (hdst[i] >= 0) Hs[hdst[i] * TT_HP + kk] = (c0 + kk < c.Cin && hoff[i] >= 0) ? rh[kk * TT_MAXNI + i] : 0.f;
+        if (t < 128) hbt[t] = sok ? ry * g.HC + rx : 0;
+        __syncthreads();
+#pragma unroll 4
+        for (int pg = 0; pg < 32; ++pg) {
+            const float a = Ys[(4 * pg + q) * TT_YP + 16 * wave + r];
+            const int hb = hbt[4 * pg + q] * TT_HP + r;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Hs[hb + ((tap / 3) * g.HC + (tap % 3)) * TT_HP], acc[tap], 0, 0, 0);
+        }
+    }
+    float *pb = partial + (size_t)slice * c.Cout * c.Kdim;
+    if (c0 + r < c.Cin) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * wave + 4 * q + i;
+                if (co < c.Cout) pb[((size_t)co * c.Cin + c0 + r) * 9 + tap] = acc[tap][i];
+            }
+    }
+}
+
 static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 KB of dynamic LDS: lift the 64 KB default once per process
     static bool done = false;
     if (!done) {
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done = true;
     }
     return PN_OK;
@@ -732,6 +820,32 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
     const long P = (long)N * c.Ho * c.Wo;
     if (c.Ho < 1 || c.Wo < 1 || P > 0x7fffffffL) return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_wgrad: size out of range");
     c.P = (int)P;
+    const int csl0 = t_slices(P, Cout);
+    TTile g;
+    if (ks == 3 && stride == 1 && pad <= 2 && Cin >= 16 && t_tile_geometry(c.Ho, c.Wo, 4, &g)) {
+        const int ntiles = N * g.tiles_x * g.tiles_y, groups = ((Cin + 15) / 16) * ((Cout + 63) / 64);
+        int S = (768 + groups - 1) / groups;
+        if (S > ntiles) S = ntiles;
+        if (S < 1) S = 1;
+        const int tps = (ntiles + S - 1) / S;
+        S = (ntiles + tps - 1) / tps;
+        const size_t wn = (size_t)Cout * c.Kdim;
+        void *ws = nullptr;
+        int rc = t_ws(ctx, wn * S * sizeof(float) + 16 + (size_t)Cout * csl0 * 2 * sizeof(double), &ws);
+        if (rc != PN_OK) return rc;
+        if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
+        hipStream_t s = (hipStream_t)hip_stream;
+        const size_t lds = (size_t)(128 * TT_YP + g.HR * g.HC * TT_HP + 128) * sizeof(float);
+        hipLaunchKernelGGL(tconv3_wgrad_tile_kernel, dim3((unsigned)((Cin + 15) / 16), (unsigned)((Cout + 63) / 64), (unsigned)S), dim3(256), lds, s, c, g, (float *)ws, tps, ntiles);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S);
+        if (dbias_dev) {
+            double *part = (double *)((char *)ws + ((wn * S * sizeof(float) + 15) & ~(size_t)15));
+            hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl0), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
+            hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl0, dbias_dev, nullptr, nullptr);
+        }
+        PN_HIP_CHECK(ctx, hipGetLastError());
+        return PN_OK;
+    }
     const int tiles = ((c.Kdim + 63) / 64) * ((Cout + 63) / 64);
     long slices = (1024 + tiles - 1) / tiles;
     const long cap = (P + 1023) / 1024;

