@@ -65,8 +65,8 @@ class HipNetModule(nn.Module):
 
     def _compile(self, device, batch, in_h, in_w):
         if self.training:
-            raise _lib.PopnetError("popnet_amd: only eval-mode inference is built (call .eval()); "
-                                   "training-mode BatchNorm / backward are not part of this path")
+            raise _lib.PopnetError("popnet_amd: module.forward is the eval-mode inference path (call .eval()); a training step "
+                                   "(train-mode BatchNorm, loss, backward, SGD) is popnet_amd.train.TrainEngine.from_module(module).step(...)")
         prec = _PREC.get(str(self.precision).lower())
         if prec is None:
             raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3', got %r" % (self.precision,))

@@ -265,6 +265,12 @@ class StreamingEngine:
         self.host = [torch.empty((self.max_batch, hitem), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.events = [torch.cuda.Event() for _ in range(self.depth)]
+        # host hand-over (submit_host): a copy stream per slot, "copied" / "no longer read" events per input buffer
+        cs = torch.cuda.Stream(device=self.device)             # ONE copy stream: transfers leave in batch order, one at a time at link rate
+        self.copy_streams = [cs for _ in range(self.depth)]
+        self._copied = [[torch.cuda.Event() for _ in range(self.pool)] for _ in range(self.depth)]
+        self._released = [[None] * self.pool for _ in range(self.depth)]
+        self._next_buf = [0] * self.depth
         self.graphs = [[None] * self.pool for _ in range(self.depth)]
         self._want_graph = bool(graph)
         self._tickets = 0
@@ -316,6 +322,26 @@ class StreamingEngine:
                 self._body(s, j)
             self.events[s].record(self.streams[s])
         self._tickets += 1
+        return t
+
+    def submit_host(self, host_batch, eager=False):
+        """Host hand-over: copies a pinned host batch into the slot's NEXT input buffer on the slot's copy stream -- ordered only
+        after the step that last read that buffer, so with pool >= 2 the PCIe transfer of this slot's next batch runs under
+        the kernels of its current one -- and runs the step once the copy has landed.  Returns the ticket."""
+        s = self._tickets % self.depth
+        j = self._next_buf[s]
+        self._next_buf[s] = (j + 1) % self.pool
+        cs = self.copy_streams[s]
+        if self._released[s][j] is not None:
+            cs.wait_event(self._released[s][j])
+        with torch.cuda.stream(cs):
+            self.inputs[s][j][:len(host_batch)].copy_(host_batch, non_blocking=True)
+            self._copied[s][j].record(cs)
+        self.streams[s].wait_event(self._copied[s][j])
+        t = self.submit(j, eager)
+        if self._released[s][j] is None:
+            self._released[s][j] = torch.cuda.Event()
+        self._released[s][j].record(self.streams[s])
         return t
 
     def wait(self, ticket):

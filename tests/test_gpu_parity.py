@@ -760,6 +760,28 @@ def test_streaming_engine_tickets_and_records(gpu, graph):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_streaming_engine_host_handover(gpu, graph):
+    """StreamingEngine.submit_host (bench.py's h2d_inclusive mode): pinned host batches copied on the copy stream into the
+    slot's next input buffer while earlier steps run; 11 DIFFERENT batches through 3 slots x 2 buffers -- every ticket's
+    records equal a plain engine's for that batch (no copy lands in a buffer a running step still reads)."""
+    from popnet_amd.pipeline import PoseEngine, StreamingEngine
+    se = StreamingEngine(PoseEngine, depth=3, pool=2, graph=graph, precision="bf16", device=gpu, max_batch=4)
+    plain = PoseEngine(precision="bf16", device=gpu, max_batch=4)
+    hosts = [torch.from_numpy(synth.synth_depth(4, 640, 480, seed=160 + i)).pin_memory() for i in range(11)]
+    want = [plain.predict(h.to(gpu)).clone() for h in hosts]
+    se.capture()
+    got = []
+    for i, h in enumerate(hosts):
+        t = se.submit_host(h)
+        with torch.cuda.stream(se.stream(t)):
+            got.append(se.records(t).clone())        # on the slot's stream, right behind the step
+    se.join()
+    torch.cuda.synchronize()
+    for i in range(11):
+        assert torch.equal(got[i], want[i]), i
+
+
 @pytest.mark.parametrize("noise,drop,sigma", [(0.03, 0.0, 0.8), (0.06, 0.2, 1.2), (0.10, 0.35, 0.6)])
 def test_parse_fuzz_noisy_planted_maps_vs_oracle(gpu, noise, drop, sigma):
     """Harsher planted maps than the golden cases (more noise -> spurious peaks and weak limbs, dropped joints, wider /
