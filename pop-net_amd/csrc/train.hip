@@ -206,9 +206,12 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < c.Cin; c0 += 16) {
-        float rh[16 * TT_MAXNI];
-        float rw[36];
+    // software pipeline: the global loads of chunk c0 + 16 stay in flight (in registers) under the 288 MFMAs of chunk c0, so a
+    // block does not depend on its CU neighbour being in the opposite phase (co-resident blocks start together and stay in
+    // lockstep: both stage, then both compute at half rate each)
+    float rh[16 * TT_MAXNI];
+    float rw[36];
+    auto load = [&](int c0) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int cok = (int)(c0 + kk < c.Cin);
@@ -224,6 +227,9 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
             const int ok = (int)(c0 + kk < c.Cin);
             rw[j] = wa[((tap * c.Cin + c0 + kk) * c.Cout) & -ok];
         }
+    };
+    load(0);
+    for (int c0 = 0; c0 < c.Cin; c0 += 16) {
         __syncthreads();                          // the previous chunk's MFMAs have read their fragments
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
@@ -236,20 +242,32 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
             As[row * TT_AP + a_co] = (a_ok && c0 + (row & 15) < c.Cin) ? rw[j] : 0.f;
         }
         __syncthreads();
+        if (c0 + 16 < c.Cin) load(c0 + 16);
+        // 9 taps x 4 k-quads; the operands of the next step are read from LDS before the 8 MFMAs of the current one issue (the
+        // compiler's own schedule was read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, every LDS latency exposed).  The tap loop is
+        // NOT unrolled: fully unrolled the hoisted LDS addresses of 36 steps push the kernel past 256 VGPRs.
+        float a[2][4], bb[2][2];
+        auto frag = [&](int tap, int ks, float (&fa)[4], float (&fb)[2]) {
+            const int ty3 = tap / 3;
+            const int toff = ty3 * g.HC + (tap - 3 * ty3);
 #pragma unroll
+            for (int m = 0; m < 4; ++m) fa[m] = As[(tap * 16 + 4 * ks + q) * TT_AP + 16 * m + r];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) fb[n] = Hs[(4 * ks + q) * g.CHP + hb[n] + toff];
+        };
+        frag(0, 0, a[0], bb[0]);
+#pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3) * g.HC + (tap % 3);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                float a[4], bb[2];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = As[(tap * 16 + 4 * ks + q) * TT_AP + 16 * m + r];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) bb[n] = Hs[(4 * ks + q) * g.CHP + hb[n] + toff];
+                if (ks < 3) frag(tap, ks + 1, a[(ks + 1) & 1], bb[(ks + 1) & 1]);
+                else frag(tap < 8 ? tap + 1 : 8, 0, a[0], bb[0]);           // (the last one re-reads tap 8: harmless)
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bb[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks & 1][m], bb[ks & 1][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // next step's 6 LDS reads ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // ... then this step's 8 MFMAs
             }
         }
     }
