@@ -145,3 +145,68 @@ class MPAugSampler:
         for r, (s, _) in enumerate(picks):
             src[r, :len(s)] = s
         return src, np.array([len(s) for s, _ in picks], dtype=np.int32), np.array([b for _, b in picks], dtype=np.int64)
+
+
+class MPAugTrainSet:
+    """The files behind KDH3D_Keypoints of the mpaug trainer (datasets_kdh3d_rtpose_mpaug.py:166-221 (CR)): several annotation
+    sets (`labels_*.json`: image id -> list of persons with `2d_joints` / `3d_joints`, plus `intrinsics`), depth frames and
+    foreground masks as `<id>` .npy files under img_dir / seg_dir, background frames listed in bg_file.  `batch(indices)` draws
+    the sources like the reference (MPAugSampler), loads them on the host and returns DEVICE tensors ready for mpaug_batch:
+    (fg_depth [B,S,H,W], fg_mask [B,S,H,W] uint8, n_src [B], bg [B,H,W], kp2d_org [B,P,15,2], kp3d [B,P,15,3], n_persons [B]).
+    The id lists are shuffled once at construction like the reference's (random.shuffle)."""
+
+    def __init__(self, img_dir, ann_file_list, bg_file, bg_dir, seg_dir, device="cuda:0", shuffle=True):
+        import json
+        self.img_dir, self.bg_dir, self.seg_dir, self.device = img_dir, bg_dir, seg_dir, torch.device(device)
+        self.annos, self.ids = [], []
+        for f in ann_file_list:
+            a = json.load(open(f, "r"))
+            ids = [k for k in a if k != "intrinsics"]
+            if shuffle:
+                random.shuffle(ids)
+            self.annos.append(a)
+            self.ids.append(ids)
+        self.bg = list(json.load(open(bg_file, "r")).values())
+        if shuffle:
+            random.shuffle(self.bg)
+        self.sampler = MPAugSampler([len(i) for i in self.ids], len(self.bg), aug_mods=[m for m in AUG_MODS if max(m) < len(self.ids)] or [[0]])
+        self.max_sources = self.sampler.max_sources
+
+    def __len__(self):
+        return max(len(i) for i in self.ids)              # dataset_len (:181)
+
+    def batch(self, indices):
+        import os
+        src, n_src, bg_id = self.sampler.batch(indices)
+        B, S = len(indices), self.max_sources
+        frames, masks, bgs, persons = [], [], [], []
+        for b in range(B):
+            fr, mk, pp = [], [], []
+            for s in range(int(n_src[b])):
+                ii, f = int(src[b, s, 0]), int(src[b, s, 1])
+                image_id = self.ids[ii][f]
+                fr.append(np.load(os.path.join(self.img_dir, image_id)))
+                mk.append(np.load(os.path.join(self.seg_dir, image_id)))
+                pp += self.annos[ii][image_id]
+            bgs.append(np.load(os.path.join(self.bg_dir, self.bg[int(bg_id[b])]["file_name"])))
+            frames.append(fr)
+            masks.append(mk)
+            persons.append(pp)
+        H, W = bgs[0].shape
+        dt = np.float16 if bgs[0].dtype == np.float16 and all(f.dtype == np.float16 for fr in frames for f in fr) else np.float32
+        fd = np.zeros((B, S, H, W), dtype=dt)
+        fm = np.zeros((B, S, H, W), dtype=np.uint8)
+        P = max(1, max(len(p) for p in persons))
+        k2 = np.zeros((B, P, NUM_JOINTS, 2), dtype=np.float32)
+        k3 = np.zeros((B, P, NUM_JOINTS, 3), dtype=np.float64)
+        npers = np.zeros(B, dtype=np.int32)
+        for b in range(B):
+            for s, (f, m) in enumerate(zip(frames[b], masks[b])):
+                fd[b, s], fm[b, s] = f, (np.asarray(m) > 0)
+            npers[b] = len(persons[b])
+            for p, ann in enumerate(persons[b]):
+                k2[b, p] = np.asarray(ann["2d_joints"], dtype=np.float32)
+                k3[b, p] = np.asarray(ann["3d_joints"], dtype=np.float64)
+        dev = self.device
+        t = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)      # noqa: E731
+        return t(fd), t(fm), t(n_src), t(np.stack(bgs).astype(dt)), t(k2), t(k3), t(npers)

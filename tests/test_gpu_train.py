@@ -345,3 +345,59 @@ def test_two_replicas_average_like_dataparallel(gpu, golden):
     _assert_same_class(*_accuracy_class(engs[0], ref, {k: (ref64[0][k] + ref64[1][k]) / 2 for k in ref64[0]}))
     # first Nesterov step: p - lr (g + mu g) = p - 1.9 g
     assert _rel(engs[0].flat_p, before - 1.9 * engs[0].flat_g) < 1e-6
+
+
+def test_train_script_on_a_fake_mpaug_dataset(gpu, tmp_path, capsys):
+    """scripts/train_mpaug.py (the reference trainer's drop-in) end to end on a fake MP-3DHP training tree: five annotation
+    sets, depth / mask / background .npy files -> composed batches and targets on the GPU -> training steps -> validation
+    loss -> `best_pose.pth` in the reference's checkpoint format, which the inference engine loads."""
+    import importlib.util
+    import json
+    import random
+    from popnet_amd import synth
+    from popnet_amd.pipeline import PoseEngine
+    d = str(tmp_path)
+    for sub in ("img", "seg", "bg"):
+        os.makedirs(os.path.join(d, sub))
+    rng = np.random.default_rng(7)
+    H, W = 320, 240
+    ann_files = []
+    for ii in range(5):
+        ann = {"intrinsics": {"fx": 504.1, "fy": 504.0, "cx": 231.7, "cy": 320.6}}
+        for f in range(6):
+            name = "s%d_%d.npy" % (ii, f)
+            joints, depths = synth.planted_persons(rng, 1, size=224)
+            j2 = joints[0] * [W / 224.0, H / 224.0]
+            ann[name] = [{"2d_joints": j2.tolist(), "3d_joints": np.concatenate([j2, np.full((15, 1), depths[0])], 1).tolist()}]
+            mask = np.zeros((H, W), dtype=np.uint8)
+            mask[max(int(j2[:, 1].min()) - 10, 0):int(j2[:, 1].max()) + 10, max(int(j2[:, 0].min()) - 10, 0):int(j2[:, 0].max()) + 10] = 1
+            np.save(os.path.join(d, "img", name), np.clip(rng.normal(depths[0], 0.1, (H, W)), 0.3, 5.9).astype(np.float16))
+            np.save(os.path.join(d, "seg", name), mask)
+        path = os.path.join(d, "ann%d.json" % ii)
+        json.dump(ann, open(path, "w"))
+        ann_files.append(path)
+    bgs = {}
+    for f in range(3):
+        np.save(os.path.join(d, "bg", "bg%d.npy" % f), np.clip(rng.normal(4.5, 0.3, (H, W)), 0, 6).astype(np.float16))
+        bgs[str(f)] = {"file_name": "bg%d.npy" % f}
+    json.dump(bgs, open(os.path.join(d, "bg.json"), "w"))
+    spec = importlib.util.spec_from_file_location("train_mpaug", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "train_mpaug.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    random.seed(1)
+    best = mod.main(["--train-annotations"] + ann_files + ["--val-annotations"] + ann_files + ["--image-dir", os.path.join(d, "img"), "--bg-file", os.path.join(d, "bg.json"),
+                    "--bg-dir", os.path.join(d, "bg"), "--seg-dir", os.path.join(d, "seg"), "--output-dir", os.path.join(d, "out"), "--batch-size", "3", "--lr", "0.05",
+                    "--epochs", "3", "--print-freq", "1", "--seed", "1"])
+    out = capsys.readouterr().out
+    vals = [float(l.split("val loss")[1].split()[0]) for l in out.splitlines() if "val loss" in l]
+    assert len(vals) == 3 and vals[-1] < vals[0] and abs(best - min(vals)) < 1e-4, out
+    sd = torch.load(os.path.join(d, "out", "best_pose.pth"), map_location="cpu")
+    assert all(k.startswith("module.") for k in sd) and len(sd) == 234
+    eng = PoseEngine(precision="fp32", state_dict=sd, device=gpu, max_batch=2, w_org=W, h_org=H)
+    recs = eng.predict(torch.from_numpy(np.stack([np.load(os.path.join(d, "img", "s0_0.npy")), np.load(os.path.join(d, "img", "s1_0.npy"))])).to(gpu))
+    assert recs.shape[0] == 2
+    # the sampler obeys the reference's control flow on this tree: one or two sources per item, masks are 0 / 1
+    from popnet_amd import targets
+    ts = targets.MPAugTrainSet(os.path.join(d, "img"), ann_files, os.path.join(d, "bg.json"), os.path.join(d, "bg"), os.path.join(d, "seg"), device=gpu)
+    fd, fm, n_src, bg, k2, k3, npers = ts.batch([0, 1, 2, 3])
+    assert fd.shape == (4, 2, H, W) and fm.dtype == torch.uint8 and int(fm.max()) == 1 and set(n_src.tolist()) <= {1, 2} and torch.equal(npers, n_src)
