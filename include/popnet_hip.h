@@ -262,7 +262,12 @@ int pn_rasterize_targets(pn_ctx *ctx, const float *kp2d_dev, const double *kp_z_
  *   pn_head_backward    dv = (d loss / d out + dextra) * d out / d v; dextra [N, dextra_ld, HW] slice or NULL
  *   pn_slice_copy       torch.cat / its gradient: copy (or add) a [N, C, HW] tensor between channel slices
  *   pn_sgd_nesterov     torch.optim.SGD(momentum, nesterov=True) on a flat buffer (train_rtpose_light3d_kdh3d_mpaug.py:313-316);
- *                       grad_scale multiplies the gradient first (1 / world size after the all-reduce) */
+ *                       grad_scale multiplies the gradient first (1 / world size after the all-reduce)
+ *   pn_train_set_precision  PN_PREC_F32 (default: every product on v_mfma_f32_16x16x4_f32, exact fp32 FMA chains) or
+ *                       PN_PREC_BF16X3: the 3x3 forward / data-gradient convolutions split every operand into two bf16
+ *                       (16 mantissa bits) and run three v_mfma_f32_16x16x32_bf16 per product block -- fp32 tensors in and
+ *                       out, results within ~1e-5 relative of the fp32 kernels, 5.3x less matrix-pipe time */
+int pn_train_set_precision(pn_ctx *ctx, int precision);
 int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const float *bias_dev, float *y_dev, int N, int Cin,
                       int H, int W, int Cout, int ks, int stride, int pad, int accumulate, void *hip_stream);
 int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float *dx_dev, int N, int Cin, int H, int W, int Cout,

@@ -385,11 +385,341 @@ __global__ __launch_bounds__(256, 2) void tconv3_wgrad_tile_kernel(TConv c, TTil
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 3x3 tile convolution on the bf16 matrix instruction with SPLIT operands ("bf16x3", opt-in through
+// pn_train_set_precision): every fp32 value v is staged as hi = bf16(v), lo = bf16(v - hi) (16 mantissa bits together) and
+// a product sum is hi*hi + hi*lo + lo*hi in fp32 accumulators (the dropped lo*lo term is 2^-16 relative) -- three
+// v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) do the work of eight v_mfma_f32_16x16x4_f32 (32 cycles each): 5.3x less
+// matrix-pipe time for fp32-class results.  Chunks of 32 input channels; LDS images are [row][32 channels] bf16 with an
+// 80-byte pitch (16-byte fragment reads and 16-byte staging writes both conflict-free); the weight slice is staged one
+// kernel row (3 taps) at a time.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 t_bf16x8 __attribute__((ext_vector_type(8)));
+#define TX_PITCH 80                     // bytes per [32 x bf16] row
+#define TX_A_BYTES (3 * 64 * TX_PITCH)  // one plane of the weight slice of one kernel row
+
+__device__ __forceinline__ void t_split8(const float (&v)[8], unsigned okmask, t_bf16x8 &hi, t_bf16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = (okmask >> j) & 1u ? v[j] : 0.f;
+        const __bf16 h = (__bf16)x;
+        hi[j] = h;
+        lo[j] = (__bf16)(x - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g, const float *__restrict__ wp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t_smem8[];
+    unsigned char *As_hi = t_smem8, *As_lo = t_smem8 + TX_A_BYTES;          // [3 taps][64 couts][32 ch]
+    unsigned char *Hs_hi = t_smem8 + 2 * TX_A_BYTES;                        // [halo pixel][32 ch]
+    unsigned char *Hs_lo = Hs_hi + g.HR * g.HC * TX_PITCH;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int b = blockIdx.x, tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
+    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = blockIdx.y * 64;
+    const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nhalo = g.HR * g.HC;
+    int hb[2], opix[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int sl = 32 * wave + 16 * n + r;
+        const int ry = sl / g.TW, rx = sl - ry * g.TW;
+        const bool ok = ry < g.R && y0 + ry < c.Ho && x0 + rx < c.Wo;
+        hb[n] = (ok ? ry * g.HC + rx : 0) * TX_PITCH + 16 * q;
+        opix[n] = ok ? (y0 + ry) * c.Wo + x0 + rx : -1;
+    }
+    // halo staging role: this wave stages channels 8 wave .. 8 wave + 7 of halo pixels lane + 64 i
+    constexpr int NH = 5;               // ceil(320 / 64): halo tiles have at most (2 + 2) x (64 + 2) = 264 pixels
+    int hoff[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int e = lane + 64 * i;
+        const int hy = e / g.HC, hx = e - hy * g.HC;
+        const int iy = y0 - c.pad + hy, ix = x0 - c.pad + hx;
+        hoff[i] = (e < nhalo && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W) ? iy * c.W + ix : -1;
+    }
+    const float *xb = c.x + (size_t)img * c.Cin * HW;
+    const int a_co = t & 63, a_g = t >> 6;      // weight staging role: cout a_co, channels 8 a_g .. 8 a_g + 7 of each tap
+    const bool a_ok = co0 + a_co < c.Cout;
+    const float *wa = wp + (a_ok ? co0 + a_co : 0);
+
+    t_f32x4 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < c.Cin; c0 += 32) {
+        const int cbase = c0 + 8 * wave;
+        unsigned cmask = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cmask |= (unsigned)(cbase + j < c.Cin) << j;
+        // ---- halo tile of 32 channels (all loads first, then split + 16-byte stores) ----
+        float hv[NH][8];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int okp = (int)(hoff[i] >= 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[i][j] = xb[((cbase + j) * HW + hoff[i]) & -(okp & (int)((cmask >> j) & 1u))];
+        }
+        __syncthreads();                              // the previous chunk's last kernel row has been consumed
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int e = lane + 64 * i;
+            if (e < nhalo) {
+                t_bf16x8 hi, lo;
+                t_split8(hv[i], hoff[i] >= 0 ? cmask : 0u, hi, lo);
+                *reinterpret_cast<t_bf16x8 *>(Hs_hi + e * TX_PITCH + 16 * wave) = hi;
+                *reinterpret_cast<t_bf16x8 *>(Hs_lo + e * TX_PITCH + 16 * wave) = lo;
+            }
+        }
+        for (int ky = 0; ky < 3; ++ky) {
+            // ---- weight slice of kernel row ky: [3 taps][64 couts][32 ch] ----
+            float wv[3][8];
+            unsigned wmask = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wmask |= (unsigned)(a_ok && c0 + 8 * a_g + j < c.Cin) << j;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    wv[kx][j] = wa[(((ky * 3 + kx) * c.Cin + c0 + 8 * a_g + j) * c.Cout) & -(int)((wmask >> j) & 1u)];
+            if (ky) __syncthreads();                  // the previous kernel row's fragments have been read
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                t_bf16x8 hi, lo;
+                t_split8(wv[kx], wmask, hi, lo);
+                *reinterpret_cast<t_bf16x8 *>(As_hi + (kx * 64 + a_co) * TX_PITCH + 16 * a_g) = hi;
+                *reinterpret_cast<t_bf16x8 *>(As_lo + (kx * 64 + a_co) * TX_PITCH + 16 * a_g) = lo;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int toff = (ky * g.HC + kx) * TX_PITCH;
+                t_bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    bh[n] = *reinterpret_cast<const t_bf16x8 *>(Hs_hi + hb[n] + toff);
+                    bl[n] = *reinterpret_cast<const t_bf16x8 *>(Hs_lo + hb[n] + toff);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int ao = (kx * 64 + 16 * m + r) * TX_PITCH + 16 * q;
+                    const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8 *>(As_hi + ao);
+                    const t_bf16x8 al = *reinterpret_cast<const t_bf16x8 *>(As_lo + ao);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int pok = (int)(opix[n] >= 0);
+        float *yb = c.y + (size_t)img * c.Cout * HoWo + (opix[n] & -pok);
+        float old[16];
+        if (c.accumulate) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + 16 * m + 4 * q + i;
+                    old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * m + 4 * q + i;
+                float v = acc[m][n][i];
+                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                if (c.accumulate) v += old[4 * m + i];
+                if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
+            }
+    }
+}
+
+static bool t_tile_geometry_x3(int Ho, int Wo, TTile *g) {       // tiles of at most 64 columns: the halo tile stays under 320 pixels
+    g->tiles_x = (Wo + 63) / 64;
+    g->TW = (Wo + g->tiles_x - 1) / g->tiles_x;
+    g->R = 128 / g->TW;
+    if (g->R > Ho) g->R = Ho;
+    if (g->R < 1) g->R = 1;
+    g->tiles_y = (Ho + g->R - 1) / g->R;
+    g->HC = g->TW + 2;
+    g->HR = g->R + 2;
+    g->NI = 0;
+    g->CHP = 0;
+    return g->HR * g->HC <= 320;
+}
+
+// Weight gradient on split-bf16 MFMA.  k = pixels, so the X operand of tap (ky, kx) is the channel-major halo row shifted by kx
+// ELEMENTS -- not a 16-byte-aligned fragment.  The halo rows are laid out so that every 8-slot pixel group starts 16-byte
+// aligned (slots per tile row rounded up to a multiple of 8, halo column 0 = image column x0 - 1); a lane reads the aligned
+// group plus the next dword once per (ky, plane) and builds the kx = 1 fragment with four v_alignbyte and the kx = 2 one by
+// renaming registers.  Block = 64 couts x (16 input channels x 9 taps), 4 pixel groups of 32 slots per tile.
+struct TTileW {
+    int TW, SW, R, tiles_x, tiles_y;    // live columns, slots per tile row (multiple of 8), rows
+    int HP, HR;                         // halo row pitch in elements (SW + 8), halo rows (R + 2)
+    int CHB;                            // bytes per halo channel
+};
+#define TXW_YP 272                      // bytes per dY row: 128 slots x bf16 + 16
+
+typedef unsigned t_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ t_bf16x8 t_as_bf16x8(t_u32x4 v) {
+    union { t_u32x4 u; t_bf16x8 b; } x;
+    x.u = v;
+    return x.b;
+}
+
+#define TXW_CI 32                       // input channels per block (two 16-column MFMA tiles per tap)
+__global__ __launch_bounds__(256, 2) void tconv3_wgrad_x3_kernel(TConv c, TTileW g, float *__restrict__ partial, int tiles_per_slice, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t_smem8[];
+    unsigned char *Yh = t_smem8, *Yl = t_smem8 + 64 * TXW_YP;                   // dY tile [64 couts][128 slots]
+    unsigned char *Xh = t_smem8 + 2 * 64 * TXW_YP, *Xl = Xh + TXW_CI * g.CHB;   // halo [32 channels][HR][HP]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int c0 = blockIdx.x * TXW_CI, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nh = g.HR * g.HP;
+    int hbq[4];                                   // byte offset (inside a channel's halo) of this lane's 8-slot group, per pixel group
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+        const int s0 = 32 * pg + 8 * q, ry = s0 / g.SW, rx0 = s0 - ry * g.SW;
+        hbq[pg] = (ry < g.R ? ry * g.HP + rx0 : 0) * 2;
+    }
+    // staging roles: dY -- slot pair (2 sp, 2 sp + 1), couts wave + 4 j;  halo -- channel t >> 3, elements (t & 7) + 8 i
+    const int sp = t & 63, s_a = 2 * sp, ry_a = s_a / g.SW, rx_a = s_a - ry_a * g.SW;
+    const int hk = t >> 3, he0 = t & 7;
+    const int hk_ok = (int)(c0 + hk < c.Cin);
+    t_f32x4 acc[2][9];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[n][k] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tbeg = slice * tiles_per_slice, tend = min(tbeg + tiles_per_slice, ntiles);
+    for (int tile = tbeg; tile < tend; ++tile) {
+        const int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, img = tile / (g.tiles_x * g.tiles_y);
+        const int y0 = ty * g.R, x0 = tx * g.TW;
+        const bool rowok = ry_a < g.R && y0 + ry_a < c.Ho;
+        const int ok0 = (int)(rowok && rx_a < g.TW && x0 + rx_a < c.Wo), ok1 = (int)(rowok && rx_a + 1 < g.TW && x0 + rx_a + 1 < c.Wo);
+        const float *dyb = c.y + (size_t)img * c.Cout * HoWo + (rowok ? (y0 + ry_a) * c.Wo + x0 + rx_a : 0);
+        const float *xb = c.x + (size_t)img * c.Cin * HW + (size_t)(hk_ok ? c0 + hk : 0) * HW;
+        float d0[16], d1[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + wave + 4 * j;
+            const int cok = (int)(co < c.Cout);
+            d0[j] = dyb[(co * HoWo) & -(ok0 & cok)];
+            d1[j] = dyb[(co * HoWo + 1) & -(ok1 & cok)];
+        }
+        __syncthreads();                          // the previous tile's fragments have been read
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + wave + 4 * j;
+            const float v0 = (ok0 && co < c.Cout) ? d0[j] : 0.f, v1 = (ok1 && co < c.Cout) ? d1[j] : 0.f;
+            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+            union { __bf16 b[2]; unsigned u; } ph, pl;
+            ph.b[0] = h0; ph.b[1] = h1; pl.b[0] = l0; pl.b[1] = l1;
+            *reinterpret_cast<unsigned *>(Yh + (wave + 4 * j) * TXW_YP + 4 * sp) = ph.u;
+            *reinterpret_cast<unsigned *>(Yl + (wave + 4 * j) * TXW_YP + 4 * sp) = pl.u;
+        }
+        {   // halo of channel hk, elements he0 + 8 i: (row, column) advance without a division; groups of 6 loads in flight (a
+            // fully unrolled all-loads-first version -- 36 values + a 64-bit mask -- spilled: 22.9 instead of 17.2 ms per step)
+            int hy = 0, hx = he0;
+            const int iy0 = y0 - c.pad, ix0 = x0 - c.pad;
+            for (int e0 = he0; e0 < nh; e0 += 48) {
+                float hv[6];
+                int okv[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int iy = iy0 + hy, ix = ix0 + hx;
+                    okv[i] = hk_ok & (int)(e0 + 8 * i < nh) & (int)(hx < g.TW + 2) & (int)(iy >= 0) & (int)(iy < c.H) & (int)(ix >= 0) & (int)(ix < c.W);
+                    hv[i] = xb[(iy * c.W + ix) & -okv[i]];
+                    hx += 8;
+                    if (hx >= g.HP) { hx -= g.HP; ++hy; }
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int e = e0 + 8 * i;
+                    if (e < nh) {
+                        const float v = okv[i] ? hv[i] : 0.f;
+                        const __bf16 h = (__bf16)v;
+                        *reinterpret_cast<__bf16 *>(Xh + hk * g.CHB + 2 * e) = h;
+                        *reinterpret_cast<__bf16 *>(Xl + hk * g.CHB + 2 * e) = (__bf16)(v - (float)h);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+            const int ao = (16 * wave + r) * TXW_YP + 64 * pg + 16 * q;
+            const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8 *>(Yh + ao), al = *reinterpret_cast<const t_bf16x8 *>(Yl + ao);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int bo = (16 * n + r) * g.CHB + hbq[pg] + ky * g.HP * 2;
+                    const t_u32x4 vh = *reinterpret_cast<const t_u32x4 *>(Xh + bo), vl = *reinterpret_cast<const t_u32x4 *>(Xl + bo);
+                    const unsigned nh4 = *reinterpret_cast<const unsigned *>(Xh + bo + 16), nl4 = *reinterpret_cast<const unsigned *>(Xl + bo + 16);
+                    t_bf16x8 bh[3], bl[3];
+                    bh[0] = t_as_bf16x8(vh);
+                    bl[0] = t_as_bf16x8(vl);
+                    bh[1] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vh[1], vh[0], 2), __builtin_amdgcn_alignbyte(vh[2], vh[1], 2),
+                                                __builtin_amdgcn_alignbyte(vh[3], vh[2], 2), __builtin_amdgcn_alignbyte(nh4, vh[3], 2)});
+                    bl[1] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vl[1], vl[0], 2), __builtin_amdgcn_alignbyte(vl[2], vl[1], 2),
+                                                __builtin_amdgcn_alignbyte(vl[3], vl[2], 2), __builtin_amdgcn_alignbyte(nl4, vl[3], 2)});
+                    bh[2] = t_as_bf16x8(t_u32x4{vh[1], vh[2], vh[3], nh4});
+                    bl[2] = t_as_bf16x8(t_u32x4{vl[1], vl[2], vl[3], nl4});
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    float *pb = partial + (size_t)slice * c.Cout * c.Kdim;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int ci = c0 + 16 * n + r;
+        if (ci >= c.Cin) continue;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * wave + 4 * q + i;
+                if (co < c.Cout) pb[((size_t)co * c.Cin + ci) * 9 + tap] = acc[n][tap][i];
+            }
+    }
+}
+
+static bool t_tile_geometry_wx3(int Ho, int Wo, TTileW *g) {
+    g->tiles_x = (Wo + 63) / 64;
+    g->TW = (Wo + g->tiles_x - 1) / g->tiles_x;
+    g->SW = (g->TW + 7) / 8 * 8;
+    g->R = 128 / g->SW;
+    if (g->R > Ho) g->R = Ho;
+    if (g->R < 1) g->R = 1;
+    g->tiles_y = (Ho + g->R - 1) / g->R;
+    g->HP = g->SW + 8;
+    g->HR = g->R + 2;
+    g->CHB = g->HR * g->HP * 2 + 16;          // + 16: the dword after the last aligned group; 16 n + 16 keeps 16-byte alignment
+    return g->SW <= 64 && 2 * 64 * TXW_YP + 2 * TXW_CI * g->CHB <= 78 * 1024;      // two blocks per CU
+}
+
 static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 KB of dynamic LDS: lift the 64 KB default once per process
     static bool done = false;
     if (!done) {
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done = true;
     }
     return PN_OK;
@@ -756,6 +1086,14 @@ static int t_slices(long total, int C) {       // slices per channel so that the
 
 extern "C" {
 
+int pn_train_set_precision(pn_ctx *ctx, int precision) {
+    T_CTX_CHECK("pn_train_set_precision")
+    if (precision != PN_PREC_F32 && precision != PN_PREC_BF16X3)
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_train_set_precision: PN_PREC_F32 or PN_PREC_BF16X3");
+    ctx->train_x3 = precision == PN_PREC_BF16X3;
+    return PN_OK;
+}
+
 int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const float *bias_dev, float *y_dev, int N, int Cin, int H, int W,
                       int Cout, int ks, int stride, int pad, int accumulate, void *hip_stream) {
     T_CTX_CHECK("pn_conv2d_forward")
@@ -781,6 +1119,13 @@ int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const
         if (rc != PN_OK) return rc;
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
         hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, 0);
+        TTile gx;
+        if (ctx->train_x3 && Cin >= 32 && t_tile_geometry_x3(c.Ho, c.Wo, &gx)) {
+            const size_t ldsx = (size_t)2 * TX_A_BYTES + (size_t)2 * gx.HR * gx.HC * TX_PITCH;
+            hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), ldsx, s, c, gx, (const float *)ws);
+            PN_HIP_CHECK(ctx, hipGetLastError());
+            return PN_OK;
+        }
         const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
         hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
         PN_HIP_CHECK(ctx, hipGetLastError());
@@ -814,6 +1159,13 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
         c.Ho = H; c.Wo = W; c.Kdim = Cout * 9; c.P = N * H * W;
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
         hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cin, Cout, 1);
+        TTile gx;
+        if (ctx->train_x3 && Cout >= 32 && t_tile_geometry_x3(H, W, &gx)) {
+            const size_t ldsx = (size_t)2 * TX_A_BYTES + (size_t)2 * gx.HR * gx.HC * TX_PITCH;
+            hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), ldsx, s, c, gx, (const float *)ws);
+            PN_HIP_CHECK(ctx, hipGetLastError());
+            return PN_OK;
+        }
         const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
         hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
         PN_HIP_CHECK(ctx, hipGetLastError());
@@ -849,15 +1201,37 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
         S = (ntiles + tps - 1) / tps;
         const size_t wn = (size_t)Cout * c.Kdim;
         void *ws = nullptr;
-        int rc = t_ws(ctx, wn * S * sizeof(float) + 16 + (size_t)Cout * csl0 * 2 * sizeof(double), &ws);
+        int rc = t_ws(ctx, wn * (size_t)(2 * S) * sizeof(float) + 16 + (size_t)Cout * csl0 * 2 * sizeof(double), &ws);   // 2 S: the split-bf16 grid has half the channel groups
         if (rc != PN_OK) return rc;
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
         hipStream_t s = (hipStream_t)hip_stream;
+        TTileW gw;
+        int Sbias = S;
+        if (ctx->train_x3 && t_tile_geometry_wx3(c.Ho, c.Wo, &gw)) {
+            // split-bf16 variant on its own tile grid (same slicing rule)
+            const int nt = N * gw.tiles_x * gw.tiles_y, groups2 = ((Cin + TXW_CI - 1) / TXW_CI) * ((Cout + 63) / 64);
+            int S2 = (768 + groups2 - 1) / groups2;
+            if (S2 > nt) S2 = nt;
+            if (S2 < 1) S2 = 1;
+            const int tps2 = (nt + S2 - 1) / S2;
+            S2 = (nt + tps2 - 1) / tps2;
+            if (S2 <= 2 * S) {                      // the partial buffer was sized for 2 S slices
+                Sbias = S2;
+                const size_t ldsw = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
+                hipLaunchKernelGGL(tconv3_wgrad_x3_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S2), dim3(256), ldsw, s, c, gw, (float *)ws, tps2, nt);
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S2);
+                goto bias;
+            }
+        }
+        {
         const size_t lds = (size_t)(128 * TT_YP + g.HR * g.HC * TT_HP + 128) * sizeof(float);
         hipLaunchKernelGGL(tconv3_wgrad_tile_kernel, dim3((unsigned)((Cin + 15) / 16), (unsigned)((Cout + 63) / 64), (unsigned)S), dim3(256), lds, s, c, g, (float *)ws, tps, ntiles);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S);
+        }
+    bias:
         if (dbias_dev) {
-            double *part = (double *)((char *)ws + ((wn * S * sizeof(float) + 15) & ~(size_t)15));
+            double *part = (double *)((char *)ws + ((wn * (size_t)(2 * S) * sizeof(float) + 15) & ~(size_t)15));
+            (void)Sbias;
             hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl0), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
             hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl0, dbias_dev, nullptr, nullptr);
         }

@@ -31,12 +31,18 @@ def _is_stat(k):
 class TrainEngine:
     """state_dict: reference-format (optionally `module.`-prefixed) rtpose_light3d(15, 14, 2, input_dim=1) checkpoint."""
 
-    def __init__(self, state_dict, device="cuda:0", lr=1.0, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1):
+    def __init__(self, state_dict, device="cuda:0", lr=1.0, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1, precision="fp32"):
+        """precision: "fp32" (every product an exact fp32 FMA chain on v_mfma_f32_16x16x4_f32) or "bf16x3" (the 3x3 forward and
+        data-gradient convolutions on split-bf16 MFMA, pn_train_set_precision: fp32 tensors, ~1e-5 relative, faster)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.PopnetError("popnet_amd.train: a ROCm device is required -- the HIP path has no CPU fallback")
         self.L = _lib.lib()
-        self.ctx = _lib.Context.for_device(self.device.index or 0)
+        self.ctx = _lib.Context(self.device.index or 0)            # private: its own scratch and precision switch
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError("precision must be 'fp32' or 'bf16x3', got %r" % (precision,))
+        self.precision = precision
+        self.ctx.check(self.L.pn_train_set_precision(self.ctx.handle, _lib.PN_PREC_BF16X3 if precision == "bf16x3" else 0), "pn_train_set_precision")
         self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
         self.group, self.world = process_group, int(world_size)
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}

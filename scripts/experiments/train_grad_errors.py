@@ -36,7 +36,7 @@ else:                       # init B: the state a run starts from, 224x224
 r32 = otrain.train_step(sd, *batch, apply=False)
 sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 r64 = otrain.train_step(sd64, *[b.double() for b in batch], apply=False, dtype=torch.float64)
-eng = TrainEngine(sd, device="cuda:0")
+eng = TrainEngine(sd, device="cuda:0", precision=os.environ.get("TRAIN_PREC", "fp32"))
 terms = eng.forward_backward(*[b.cuda() for b in batch]).cpu().numpy()
 print("terms hip", terms, "\nterms f32", r32["terms"], "\nterms f64", r64["terms"])
 rows = []
