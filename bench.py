@@ -186,14 +186,14 @@ def train_step_cpu(batch, threads=32):
     return {"ms_per_step": round(dt * 1e3, 1), "frames_per_s": round(len(cpu[0]) / dt, 2), "cores": threads, "kind": "port"}
 
 
-def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=False):
+def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=False, precision="fp32", batch_in=None):
     """BASELINE configs[4]: one training step of rtpose_light3d (train-mode forward, rtpose_light3d_loss_fgweight, backward,
     Nesterov SGD; popnet_amd.train.TrainEngine, fp32, every kernel hand-written HIP) on BATCH frames of 224 x 224 per rank from the
     reference's initial state, targets built on the GPU; with world > 1 the flat 22 MB gradient is all-reduced every step."""
     from popnet_amd import synth
     from popnet_amd.train import TrainEngine
-    batch, t_targets = synth_training_batch(dev, BATCH)
-    eng = TrainEngine(synth.init_like_state_dict(seed=3), device=dev, lr=lr, world_size=world, process_group=group)
+    batch, t_targets = batch_in if batch_in is not None else synth_training_batch(dev, BATCH)
+    eng = TrainEngine(synth.init_like_state_dict(seed=3), device=dev, lr=lr, world_size=world, process_group=group, precision=precision)
     first = None
     for k in range(warmup):
         t = eng.step(*batch)
@@ -210,6 +210,10 @@ def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=Fal
     dt = (time.perf_counter() - t0) / steps
     flops = 3 * 13.343e9 * BATCH                                     # forward + data gradient + weight gradient, SURVEY 8d's per-frame figure
     extra = {"cpu_baseline": train_step_cpu(batch)} if cpu else {}
+    if precision == "fp32" and batch_in is None and world == 1:      # the opt-in fast mode on the same batch, next to the parity mode
+        fast = train_step_leg(dev, steps, warmup, world, group, lr, False, "bf16x3", (batch, t_targets))
+        extra["bf16x3"] = {k: fast[k] for k in ("ms_per_step", "frames_per_s_per_gpu", "tflops", "loss_first_step", "loss_last_step")}
+        extra["bf16x3"]["what"] = "TrainEngine(precision='bf16x3'): the 3x3 convolutions (forward, data and weight gradient) on split-bf16 MFMA, fp32 tensors"
     return {**extra, "ms_per_step": round(dt * 1e3, 3), "frames_per_s_per_gpu": round(BATCH / dt, 1), "tflops": round(flops / dt / 1e12, 1), "dtype": "f32",
             "peak_tflops_f32_mfma": 157.0, "batch_per_gpu": BATCH, "input": "224x224", "parameters": int(eng.flat_p.numel()),
             "loss_first_step": round(first, 5), "loss_last_step": round(float(t.sum()), 5), "targets_on_gpu_ms_per_batch": round(t_targets * 1e3, 3),

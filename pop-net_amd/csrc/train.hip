@@ -1194,7 +1194,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
     TTile g;
     if (ks == 3 && stride == 1 && pad <= 2 && Cin >= 16 && t_tile_geometry(c.Ho, c.Wo, 4, &g)) {
         const int ntiles = N * g.tiles_x * g.tiles_y, groups = ((Cin + 15) / 16) * ((Cout + 63) / 64);
-        int S = (768 + groups - 1) / groups;
+        int S = (512 + groups - 1) / groups;             // two blocks per CU: 512 fill the chip
         if (S > ntiles) S = ntiles;
         if (S < 1) S = 1;
         const int tps = (ntiles + S - 1) / S;
@@ -1210,7 +1210,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
         if (ctx->train_x3 && t_tile_geometry_wx3(c.Ho, c.Wo, &gw)) {
             // split-bf16 variant on its own tile grid (same slicing rule)
             const int nt = N * gw.tiles_x * gw.tiles_y, groups2 = ((Cin + TXW_CI - 1) / TXW_CI) * ((Cout + 63) / 64);
-            int S2 = (768 + groups2 - 1) / groups2;
+            int S2 = (512 + groups2 - 1) / groups2;         // two blocks per CU: 512 fill the chip; fewer slices = less partial-sum traffic
             if (S2 > nt) S2 = nt;
             if (S2 < 1) S2 = 1;
             const int tps2 = (nt + S2 - 1) / S2;
