@@ -924,6 +924,18 @@ __global__ void sums_finish_kernel(const double *__restrict__ partial, int C, in
     if (out1) out1[ch] = (float)(invstd ? ss * (double)invstd[ch] : ss);   // d gamma = sum g (x - mean) * invstd
 }
 
+// BatchNorm backward: d beta = sum g, raw sum g (x - mean) for the apply kernel, d gamma = that * invstd -- one launch
+__global__ void bn_bwd_finish_kernel(const double *__restrict__ partial, int C, int slices, const float *__restrict__ invstd, float *__restrict__ dbeta,
+                                     float *__restrict__ sum_gx, float *__restrict__ dgamma) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    dbeta[ch] = (float)s;
+    sum_gx[ch] = (float)ss;
+    dgamma[ch] = (float)(ss * (double)invstd[ch]);
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                                 const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ res, int act,
                                 int C, int HW, float *__restrict__ y) {
@@ -1304,8 +1316,7 @@ int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, c
     hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, dy_dev, out_dev, save_mean_dev, act, N, C, HW, sl, (double *)ws);
     // d beta = sum g, sum g (x - mean) (raw, into the scratch) and d gamma = that * invstd
     float *sgx = (float *)((char *)ws + (size_t)C * sl * 2 * sizeof(double));
-    hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, dbeta_dev, sgx, nullptr);
-    hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, nullptr, dgamma_dev, save_invstd_dev);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, save_invstd_dev, dbeta_dev, sgx, dgamma_dev);
     if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: N * C out of range");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, save_mean_dev,
                        save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);

@@ -268,11 +268,20 @@ class TrainEngine:
             self.tracked[k] += 1
         return self.loss_terms
 
+    @staticmethod
+    def reduce_flat_gradient(flat_g, world, group=None):
+        """The data-parallel exchange of a step: ONE all-reduce (sum) of the flat gradient buffer over the replicas; the 1 / world
+        of DataParallel's mean is applied inside pn_sgd_nesterov (grad_scale).  Returns that scale.  (RCCL on the GPUs; the
+        world_size-2 gloo test drives exactly this function on CPU tensors.)"""
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flat_g, group=group)
+        return 1.0 / world
+
     def apply(self):
         """Average the gradient over the replicas (one all-reduce of the flat buffer) and take the Nesterov SGD step."""
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_g, group=self.group)
+            self.reduce_flat_gradient(self.flat_g, self.world, self.group)
         self._check(self.L.pn_sgd_nesterov(self.ctx.handle, self._ptr(self.flat_p), self._ptr(self.flat_g), self._ptr(self.flat_m), self.flat_p.numel(), self.lr, self.momentum,
                                            self.weight_decay, 1 if self.steps == 0 else 0, 1.0 / self.world, self._s()), "pn_sgd_nesterov")
         self.steps += 1

@@ -119,3 +119,29 @@ def test_torchrun_command_shape():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-3:] == ["bench.py", "--gpus", "4"]
+
+
+def _train_dp_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import popnet_amd  # noqa: F401
+    from popnet_amd.train import TrainEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(5525814, generator=g)                       # this replica's gradient of its half batch (flat buffer, as TrainEngine holds it)
+    mine = flat.clone()
+    scale = TrainEngine.reduce_flat_gradient(flat, world)          # what TrainEngine.apply does before pn_sgd_nesterov(grad_scale=scale)
+    other = torch.randn(5525814, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+    ret[rank] = bool(scale == 0.5 and torch.allclose(flat * scale, (mine + other) / 2, rtol=0, atol=1e-6))
+    dist.destroy_process_group()
+
+
+def test_training_gradient_exchange_world2_gloo():
+    """Data-parallel training: every replica ends up with the MEAN of the replicas' gradients -- one all-reduce of the
+    flat 5 525 814-float buffer, then the 1 / world scale that pn_sgd_nesterov applies.  The function under test is the one
+    TrainEngine.apply calls (RCCL on the GPUs, gloo here)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_dp_worker, args=(2, 29500 + (os.getpid() % 1000) + 11, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
