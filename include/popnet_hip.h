@@ -246,6 +246,8 @@ int pn_rasterize_targets(pn_ctx *ctx, const float *kp2d_dev, const double *kp_z_
  * fp32, NCHW, contiguous -- the layout of the reference's own tensors, so every intermediate can be laid next to the
  * reference module's.  One entry per differentiable primitive of rtpose_light3d in train mode; popnet_amd/train.py
  * strings them together (forward, rtpose_light3d_loss_fgweight, backward, Nesterov SGD).  All asynchronous on the stream.
+ * They share ONE scratch buffer inside the pn_ctx (rotated weights, split-reduction partials), reused in stream order: drive a
+ * pn_ctx's training primitives from one stream at a time (TrainEngine owns a private pn_ctx for that reason).
  *   pn_conv2d_forward   nn.Conv2d (tpm/lib/network/rtpose_light3d.py:31-40,144,232-246): kernel 1 / 3 / 7, any stride and
  *                       padding; accumulate != 0 adds into y.  w [Cout, Cin, k, k], bias [Cout] or NULL.
  *   pn_conv2d_dgrad     its input gradient (stride 1): dx [N,Cin,H,W] (+)= conv_transpose(dy [N,Cout,Ho,Wo], w)

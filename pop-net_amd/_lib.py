@@ -188,6 +188,14 @@ class Context:
             ctx = cls._cache[device_index] = cls(device_index)
         return ctx
 
+    def __del__(self):                     # private contexts (engines that own their scratch) release it; the per-device ones live on
+        try:
+            if self.handle and Context._cache.get(self.device_index) is not self:
+                lib().pn_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
     def last_error(self):
         buf = C.create_string_buffer(1024)
         lib().pn_last_error(self.handle, buf, 1024)

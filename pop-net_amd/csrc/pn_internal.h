@@ -16,6 +16,7 @@ struct pn_ctx {
     // scratch of the training kernels (flipped weights, split-reduction partials; train.hip), stream-ordered reuse
     void *train_ws = nullptr;
     size_t train_ws_bytes = 0;
+    bool train_lds_attr = false;     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the tile kernels on this device
     bool train_x3 = false;           // pn_train_set_precision: 3x3 forward / data-gradient convolutions on split-bf16 MFMA
 };
 

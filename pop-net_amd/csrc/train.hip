@@ -713,8 +713,8 @@ static bool t_tile_geometry_wx3(int Ho, int Wo, TTileW *g) {
     return g->SW <= 64 && 2 * 64 * TXW_YP + 2 * TXW_CI * g->CHB <= 78 * 1024;      // two blocks per CU
 }
 
-static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 KB of dynamic LDS: lift the 64 KB default once per process
-    static bool done = false;
+static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 KB of dynamic LDS: lift the 64 KB default once per context (= per device)
+    bool &done = ctx->train_lds_attr;
     if (!done) {
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1218,7 +1218,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
         hipStream_t s = (hipStream_t)hip_stream;
         TTileW gw;
-        int Sbias = S;
+        bool done = false;
         if (ctx->train_x3 && t_tile_geometry_wx3(c.Ho, c.Wo, &gw)) {
             // split-bf16 variant on its own tile grid (same slicing rule)
             const int nt = N * gw.tiles_x * gw.tiles_y, groups2 = ((Cin + TXW_CI - 1) / TXW_CI) * ((Cout + 63) / 64);
@@ -1228,22 +1228,19 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
             const int tps2 = (nt + S2 - 1) / S2;
             S2 = (nt + tps2 - 1) / tps2;
             if (S2 <= 2 * S) {                      // the partial buffer was sized for 2 S slices
-                Sbias = S2;
                 const size_t ldsw = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
                 hipLaunchKernelGGL(tconv3_wgrad_x3_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S2), dim3(256), ldsw, s, c, gw, (float *)ws, tps2, nt);
                 hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S2);
-                goto bias;
+                done = true;
             }
         }
-        {
-        const size_t lds = (size_t)(128 * TT_YP + g.HR * g.HC * TT_HP + 128) * sizeof(float);
-        hipLaunchKernelGGL(tconv3_wgrad_tile_kernel, dim3((unsigned)((Cin + 15) / 16), (unsigned)((Cout + 63) / 64), (unsigned)S), dim3(256), lds, s, c, g, (float *)ws, tps, ntiles);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S);
+        if (!done) {
+            const size_t lds = (size_t)(128 * TT_YP + g.HR * g.HC * TT_HP + 128) * sizeof(float);
+            hipLaunchKernelGGL(tconv3_wgrad_tile_kernel, dim3((unsigned)((Cin + 15) / 16), (unsigned)((Cout + 63) / 64), (unsigned)S), dim3(256), lds, s, c, g, (float *)ws, tps, ntiles);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S);
         }
-    bias:
         if (dbias_dev) {
             double *part = (double *)((char *)ws + ((wn * (size_t)(2 * S) * sizeof(float) + 15) & ~(size_t)15));
-            (void)Sbias;
             hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl0), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
             hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl0, dbias_dev, nullptr, nullptr);
         }
