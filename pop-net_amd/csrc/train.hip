@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_wgrad_tile_kernel(TConv c, TTil
 // kernel row (3 taps) at a time.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __bf16 t_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned t_u32x4 __attribute__((ext_vector_type(4)));
 #define TX_PITCH 80                     // bytes per [32 x bf16] row
 #define TX_A_BYTES (3 * 64 * TX_PITCH)  // one plane of the weight slice of one kernel row
 
@@ -408,7 +409,24 @@ __device__ __forceinline__ void t_split8(const float (&v)[8], unsigned okmask, t
     }
 }
 
-__global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g, const float *__restrict__ wp) {
+// Weights of the split-bf16 kernel, packed once per launch in the LDS image's own order: wpx[plane][chunk of 32 ci][tap][cout][32 ci]
+// bf16 (plane 0 = hi, 1 = lo; channels beyond Cin are zero), so that staging a kernel row is six 16-byte copies per thread instead
+// of 24 dword loads + the split arithmetic per thread.  flip as in wpack3_kernel (the data gradient's rotated, transposed weights).
+__global__ void wpack3_x3_kernel(const float *__restrict__ w, __bf16 *__restrict__ wpx, int Cout, int Cin, int flip) {
+    const int chunks = (Cin + 31) / 32;
+    const size_t plane = (size_t)chunks * 9 * Cout * 32;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const int ch = (int)(i & 31), co = (int)((i >> 5) % Cout), tap = (int)(((i >> 5) / Cout) % 9), chunk = (int)((i >> 5) / Cout / 9);
+    const int ci = chunk * 32 + ch;
+    float v = 0.f;
+    if (ci < Cin) v = flip ? w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : w[((size_t)co * Cin + ci) * 9 + tap];
+    const __bf16 h = (__bf16)v;
+    wpx[i] = h;
+    wpx[plane + i] = (__bf16)(v - (float)h);
+}
+
+__global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g, const __bf16 *__restrict__ wpx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char t_smem8[];
     unsigned char *As_hi = t_smem8, *As_lo = t_smem8 + TX_A_BYTES;          // [3 taps][64 couts][32 ch]
     unsigned char *Hs_hi = t_smem8 + 2 * TX_A_BYTES;                        // [halo pixel][32 ch]
@@ -437,9 +455,8 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
         hoff[i] = (e < nhalo && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W) ? iy * c.W + ix : -1;
     }
     const float *xb = c.x + (size_t)img * c.Cin * HW;
-    const int a_co = t & 63, a_g = t >> 6;      // weight staging role: cout a_co, channels 8 a_g .. 8 a_g + 7 of each tap
-    const bool a_ok = co0 + a_co < c.Cout;
-    const float *wa = wp + (a_ok ? co0 + a_co : 0);
+    // weight staging role: per kernel row 3 taps x 64 couts x 4 segments of 8 channels x 2 planes = 1536 16-byte pieces, 6 per thread
+    const size_t wplane = (size_t)((c.Cin + 31) / 32) * 9 * c.Cout * 32;
 
     t_f32x4 acc[4][2];
 #pragma unroll
@@ -472,23 +489,24 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
             }
         }
         for (int ky = 0; ky < 3; ++ky) {
-            // ---- weight slice of kernel row ky: [3 taps][64 couts][32 ch] ----
-            float wv[3][8];
-            unsigned wmask = 0;
+            // ---- weight slice of kernel row ky: [3 taps][64 couts][32 ch], straight 16-byte copies of the packed planes ----
+            t_u32x4 wv[6];
+            const __bf16 *wrow = wpx + ((size_t)(c0 >> 5) * 9 + ky * 3) * c.Cout * 32;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wmask |= (unsigned)(a_ok && c0 + 8 * a_g + j < c.Cin) << j;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    wv[kx][j] = wa[(((ky * 3 + kx) * c.Cin + c0 + 8 * a_g + j) * c.Cout) & -(int)((wmask >> j) & 1u)];
+            for (int j = 0; j < 6; ++j) {
+                const int piece = t + 256 * j;                    // < 1536: plane, kx, cout, segment
+                const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
+                const int ok = (int)(co0 + co < c.Cout);
+                const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
+                wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
+                if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
+            }
             if (ky) __syncthreads();                  // the previous kernel row's fragments have been read
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                t_bf16x8 hi, lo;
-                t_split8(wv[kx], wmask, hi, lo);
-                *reinterpret_cast<t_bf16x8 *>(As_hi + (kx * 64 + a_co) * TX_PITCH + 16 * a_g) = hi;
-                *reinterpret_cast<t_bf16x8 *>(As_lo + (kx * 64 + a_co) * TX_PITCH + 16 * a_g) = lo;
+            for (int j = 0; j < 6; ++j) {
+                const int piece = t + 256 * j;
+                const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
+                *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + (kx * 64 + co) * TX_PITCH + 16 * seg) = wv[j];
             }
             __syncthreads();
 #pragma unroll
@@ -568,7 +586,6 @@ struct TTileW {
 };
 #define TXW_YP 272                      // bytes per dY row: 128 slots x bf16 + 16
 
-typedef unsigned t_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ t_bf16x8 t_as_bf16x8(t_u32x4 v) {
     union { t_u32x4 u; t_bf16x8 b; } x;
@@ -1126,18 +1143,20 @@ int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const
     if (ks == 3 && stride == 1 && pad <= 2 && Cin >= 16 && t_tile_geometry(c.Ho, c.Wo, 16, &g)) {
         // second-generation 3x3 kernel: weights to [tap][ci][cout] in the scratch, then halo tiles
         const size_t wn = (size_t)Cout * Cin * 9;
+        const size_t wx = (size_t)((Cin + 31) / 32) * 9 * Cout * 32;        // elements per plane of the split-bf16 pack
         void *ws = nullptr;
-        int rc = t_ws(ctx, wn * sizeof(float), &ws);
+        int rc = t_ws(ctx, wn * sizeof(float) > 4 * wx ? wn * sizeof(float) : 4 * wx, &ws);
         if (rc != PN_OK) return rc;
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
-        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, 0);
         TTile gx;
         if (ctx->train_x3 && Cin >= 32 && t_tile_geometry_x3(c.Ho, c.Wo, &gx)) {
+            hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cout, Cin, 0);
             const size_t ldsx = (size_t)2 * TX_A_BYTES + (size_t)2 * gx.HR * gx.HC * TX_PITCH;
-            hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), ldsx, s, c, gx, (const float *)ws);
+            hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), ldsx, s, c, gx, (const __bf16 *)ws);
             PN_HIP_CHECK(ctx, hipGetLastError());
             return PN_OK;
         }
+        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, 0);
         const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
         hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
         PN_HIP_CHECK(ctx, hipGetLastError());
@@ -1158,8 +1177,9 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
         return pn_set_error(ctx, PN_ERR_INVALID, "pn_conv2d_dgrad: bad arguments (stride 1 only)");
     const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
     const size_t wn = (size_t)Cout * Cin * ks * ks;
+    const size_t wx = (size_t)((Cout + 31) / 32) * 9 * Cin * 32;          // elements per plane of the split-bf16 pack (conv input channels = Cout)
     void *ws = nullptr;
-    int rc = t_ws(ctx, wn * sizeof(float), &ws);
+    int rc = t_ws(ctx, (ks == 3 && 4 * wx > wn * sizeof(float)) ? 4 * wx : wn * sizeof(float), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     TTile g;
@@ -1170,14 +1190,15 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
         c.N = N; c.Cin = Cout; c.H = Ho; c.W = Wo; c.Cout = Cin; c.stride = 1; c.pad = 2 - pad; c.accumulate = accumulate;
         c.Ho = H; c.Wo = W; c.Kdim = Cout * 9; c.P = N * H * W;
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
-        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cin, Cout, 1);
         TTile gx;
         if (ctx->train_x3 && Cout >= 32 && t_tile_geometry_x3(H, W, &gx)) {
+            hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cin, Cout, 1);
             const size_t ldsx = (size_t)2 * TX_A_BYTES + (size_t)2 * gx.HR * gx.HC * TX_PITCH;
-            hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), ldsx, s, c, gx, (const float *)ws);
+            hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), ldsx, s, c, gx, (const __bf16 *)ws);
             PN_HIP_CHECK(ctx, hipGetLastError());
             return PN_OK;
         }
+        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cin, Cout, 1);
         const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
         hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
         PN_HIP_CHECK(ctx, hipGetLastError());
