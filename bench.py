@@ -194,11 +194,10 @@ def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=Fal
     from popnet_amd.train import TrainEngine
     batch, t_targets = batch_in if batch_in is not None else synth_training_batch(dev, BATCH)
     eng = TrainEngine(synth.init_like_state_dict(seed=3), device=dev, lr=lr, world_size=world, process_group=group, precision=precision)
-    first = None
+    first = float(eng.step(*batch).sum())
+    eng.capture(*batch)                                              # the step as one hipGraph (two more eager steps inside)
     for k in range(warmup):
         t = eng.step(*batch)
-        if first is None:
-            first = float(t.sum())
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -217,6 +216,7 @@ def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=Fal
     return {**extra, "ms_per_step": round(dt * 1e3, 3), "frames_per_s_per_gpu": round(BATCH / dt, 1), "tflops": round(flops / dt / 1e12, 1), "dtype": "f32",
             "peak_tflops_f32_mfma": 157.0, "batch_per_gpu": BATCH, "input": "224x224", "parameters": int(eng.flat_p.numel()),
             "loss_first_step": round(first, 5), "loss_last_step": round(float(t.sum()), 5), "targets_on_gpu_ms_per_batch": round(t_targets * 1e3, 3),
+            "launch_mode": "hipGraph replay of the step" if world == 1 else "hipGraph replay of forward + backward, all-reduce and update eager",
             "what": "TrainEngine.step: train-mode forward (batch-statistics BatchNorm), fg-weighted loss, backward (MFMA dgrad / wgrad), Nesterov SGD; %s"
                     % ("one all-reduce of the flat gradient per step over %d ranks" % world if world > 1 else "single GPU")}
 

@@ -65,6 +65,7 @@ class TrainEngine:
         self.A = {}            # activations of the current step
         self._bufs = {}        # name -> tensor, reused across steps while the shape stays
         self.loss_terms = torch.zeros(6, dtype=torch.float32, device=self.device)
+        self._graph, self._static = None, None
 
     @classmethod
     def from_module(cls, module, **kw):
@@ -287,10 +288,48 @@ class TrainEngine:
         self.steps += 1
 
     def step(self, img, heat_gt, paf_gt, z_gt, fg_mask):
-        """-> device tensor [6] of loss terms (LOSS_NAMES); the total loss of losses.py:65-90 is their sum.  Asynchronous."""
+        """-> device tensor [6] of loss terms (LOSS_NAMES); the total loss of losses.py:65-90 is their sum.  Asynchronous.
+        After capture() a batch of the captured shape replays the hipGraph instead of issuing ~430 launches from Python."""
+        if self._graph is not None and tuple(img.shape) == tuple(self._static[0].shape):
+            for dst, src in zip(self._static, (img, heat_gt, paf_gt, z_gt, fg_mask)):
+                dst.copy_(src, non_blocking=True)
+            self._graph.replay()
+            for k in self.tracked:
+                self.tracked[k] += 1
+            if self.world > 1:                       # the exchange and the update stay outside the graph
+                self.apply()
+            else:
+                self.steps += 1
+            return self.loss_terms
         terms = self.forward_backward(img, heat_gt, paf_gt, z_gt, fg_mask)
         self.apply()
         return terms
+
+    def capture(self, img, heat_gt, paf_gt, z_gt, fg_mask):
+        """Captures one step for this batch shape in a hipGraph (forward, loss, backward and -- single GPU -- the SGD update;
+        with world > 1 the gradient all-reduce and the update stay eager behind the graph).  Runs two eager steps first: every
+        buffer and the C-side scratch reach their final size, the momentum buffers exist (the graph bakes in first_step = 0).
+        The learning rate is baked in too: call capture() again after changing `lr`."""
+        batch = (img, heat_gt, paf_gt, z_gt, fg_mask)
+        self._graph = None
+        for _ in range(2):
+            self.step(*batch)
+        torch.cuda.synchronize(self.device)
+        self._static = [t.clone() for t in batch]
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                self.forward_backward(*self._static)
+                if self.world == 1:
+                    self._check(self.L.pn_sgd_nesterov(self.ctx.handle, self._ptr(self.flat_p), self._ptr(self.flat_g), self._ptr(self.flat_m), self.flat_p.numel(), self.lr,
+                                                       self.momentum, self.weight_decay, 0, 1.0, self._s()), "pn_sgd_nesterov")
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        for k in self.tracked:                       # forward_backward counted the captured (not executed) pass
+            self.tracked[k] -= 1
+        self._graph = g
+        return self
 
     def state_dict(self, prefix=""):
         """Reference-format checkpoint (train_rtpose_light3d_kdh3d_mpaug.py:337 saves the DataParallel one: prefix='module.')."""

@@ -23,6 +23,8 @@ rng = np.random.default_rng(1)
 batch = [torch.from_numpy(a).to(dev) for a in (rng.normal(0, 1, (B, 1, 224, 224)).astype(np.float32), rng.uniform(0, 1, (B, 16, 28, 28)).astype(np.float32),
                                               rng.uniform(-1, 1, (B, 28, 28, 28)).astype(np.float32), rng.uniform(-1.5, 1.5, (B, 15, 28, 28)).astype(np.float32),
                                               (rng.uniform(0, 1, (B, 15, 28, 28)) < 0.2).astype(np.float32))]
+if os.environ.get("TRAIN_GRAPH", "1") != "0":
+    eng.capture(*batch)
 for _ in range(2):
     t = eng.step(*batch)
 torch.cuda.synchronize()
@@ -33,3 +35,11 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 flops = 3 * 13.343e9 * B          # forward + data gradient + weight gradient (13.343 GFLOP per frame forward)
 print(prec, "B=%d  %.2f ms/step  %.0f frames/s  %.1f TFLOP/s (3 x forward FLOPs)  loss terms %s" % (B, dt * 1e3, B / dt, flops / dt / 1e12, t.cpu().numpy()))
+# host-side enqueue time per step (how far the Python loop runs ahead of the GPU)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    eng.step(*batch)
+host = (time.perf_counter() - t0) / steps
+torch.cuda.synchronize()
+print("host enqueue %.2f ms/step" % (host * 1e3))

@@ -431,3 +431,26 @@ def test_train_script_on_a_fake_mpaug_dataset(gpu, tmp_path, capsys):
     ts = targets.MPAugTrainSet(os.path.join(d, "img"), ann_files, os.path.join(d, "bg.json"), os.path.join(d, "bg"), os.path.join(d, "seg"), device=gpu)
     fd, fm, n_src, bg, k2, k3, npers = ts.batch([0, 1, 2, 3])
     assert fd.shape == (4, 2, H, W) and fm.dtype == torch.uint8 and int(fm.max()) == 1 and set(n_src.tolist()) <= {1, 2} and torch.equal(npers, n_src)
+
+
+def test_captured_training_step_equals_eager(gpu, golden):
+    """TrainEngine.capture: the whole step as one hipGraph replay -- same parameters, statistics and loss terms as the eager
+    engine after the same five steps on changing batches (bit for bit: same kernels, same order)."""
+    from popnet_amd.train import TrainEngine
+    sd = init_like_state_dict(golden.keys["rtpose_light3d"], seed=4)
+    batches = [[torch.from_numpy(a).to(gpu) for a in train_case_inputs(seed=500 + i, B=2, H=64, W=96)] for i in range(5)]
+    eager, graph = TrainEngine(sd, device=gpu, lr=0.05), TrainEngine(sd, device=gpu, lr=0.05)
+    graph.capture(*batches[0])                       # two warm-up steps on batch 0 inside
+    for _ in range(2):
+        eager.step(*batches[0])
+    for b in batches:
+        te = eager.step(*b).clone()
+        tg = graph.step(*b).clone()
+        assert torch.equal(te, tg)
+    torch.cuda.synchronize()
+    assert torch.equal(eager.flat_p, graph.flat_p) and torch.equal(eager.flat_m, graph.flat_m)
+    a, b = eager.state_dict(), graph.state_dict()
+    assert all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a) and int(b["model0.bn1.num_batches_tracked"]) == 7
+    # another batch shape falls back to the eager path
+    other = [torch.from_numpy(x).to(gpu) for x in train_case_inputs(seed=9, B=1, H=64, W=96)]
+    assert torch.equal(eager.step(*other), graph.step(*other))
