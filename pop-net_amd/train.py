@@ -305,14 +305,17 @@ class TrainEngine:
         self.apply()
         return terms
 
-    def capture(self, img, heat_gt, paf_gt, z_gt, fg_mask):
+    def capture(self, img, heat_gt, paf_gt, z_gt, fg_mask, warmup_steps=2):
         """Captures one step for this batch shape in a hipGraph (forward, loss, backward and -- single GPU -- the SGD update;
         with world > 1 the gradient all-reduce and the update stay eager behind the graph).  Runs two eager steps first: every
         buffer and the C-side scratch reach their final size, the momentum buffers exist (the graph bakes in first_step = 0).
-        The learning rate is baked in too: call capture() again after changing `lr`."""
+        The learning rate is baked in too: call capture() again after changing `lr`.  warmup_steps = 0 captures without
+        executing anything (an engine that has already stepped on this batch shape: the training loop's case)."""
         batch = (img, heat_gt, paf_gt, z_gt, fg_mask)
         self._graph = None
-        for _ in range(2):
+        if warmup_steps == 0 and self.steps == 0:
+            raise _lib.PopnetError("popnet_amd.train: capture(warmup_steps=0) needs an engine that has already taken a step")
+        for _ in range(warmup_steps):
             self.step(*batch)
         torch.cuda.synchronize(self.device)
         self._static = [t.clone() for t in batch]

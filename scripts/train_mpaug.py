@@ -106,7 +106,7 @@ def main(argv=None):
     eng = TrainEngine.from_module(module, device=dev, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay, world_size=world)
     module = module.to(dev).eval()
     module.precision = "fp32"
-    plateau, best = Plateau(), float("inf")
+    plateau, best, captured_lr = Plateau(), float("inf"), None
     os.makedirs(args.output_dir, exist_ok=True)
     per_rank = args.batch_size // world               # DataParallel splits the batch over the replicas
     for epoch in range(args.epochs):
@@ -116,8 +116,11 @@ def main(argv=None):
         t0, run = time.time(), 0.0
         for i in range(n_batches):
             mine = order[i * args.batch_size + rank * per_rank: i * args.batch_size + (rank + 1) * per_rank]
-            batch = targets.mpaug_batch(*train_set.batch(mine), input_size=args.square_edge, z_radius=args.z_radius)
-            terms = eng.step(*[t.contiguous() for t in batch])
+            batch = [t.contiguous() for t in targets.mpaug_batch(*train_set.batch(mine), input_size=args.square_edge, z_radius=args.z_radius)]
+            if eng.steps >= 1 and captured_lr != eng.lr:          # the step as one hipGraph (re-captured when the plateau rule moved lr)
+                eng.capture(*batch, warmup_steps=0)
+                captured_lr = eng.lr
+            terms = eng.step(*batch)
             if i % args.print_freq == 0 and rank == 0:
                 tl = terms.cpu().tolist()
                 run = sum(tl)
