@@ -154,17 +154,18 @@ def test_avgpool_head_sgd_vs_torch(gpu):
     assert abs(float(loss) - float(loss_r.detach())) < 1e-6 * float(loss_r.detach())
     ctx.check(L.pn_head_backward(ctx.handle, _p(sg), _p(td), _p(fgd), C.c_void_p(exd.data_ptr() + 7 * h * w * 4), LD, 1, N, Cc, h * w, _p(dv), s), "head bwd")
     assert _rel(dv, v.grad) < 1e-5
-    # Nesterov SGD, two steps, against torch.optim.SGD
-    p = torch.randn(1000, generator=g)
-    pr = p.clone().requires_grad_()
-    opt = torch.optim.SGD([pr], lr=0.7, momentum=0.9, nesterov=True)
-    pd, buf = p.to(gpu), torch.zeros(1000, device=gpu)
-    for k in range(3):
-        gr = torch.randn(1000, generator=g)
-        pr.grad = gr.clone()
-        opt.step()
-        ctx.check(L.pn_sgd_nesterov(ctx.handle, _p(pd), _p((gr * 2).to(gpu)), _p(buf), 1000, 0.7, 0.9, 0.0, 1 if k == 0 else 0, 0.5, s), "sgd")
-        assert _rel(pd, pr.detach()) < 1e-6
+    # Nesterov SGD, three steps, against torch.optim.SGD -- without and with weight decay (--weight-decay of the trainer)
+    for wd in (0.0, 1e-2):
+        p = torch.randn(1000, generator=g)
+        pr = p.clone().requires_grad_()
+        opt = torch.optim.SGD([pr], lr=0.7, momentum=0.9, nesterov=True, weight_decay=wd)
+        pd, buf = p.to(gpu), torch.zeros(1000, device=gpu)
+        for k in range(3):
+            gr = torch.randn(1000, generator=g)
+            pr.grad = gr.clone()
+            opt.step()
+            ctx.check(L.pn_sgd_nesterov(ctx.handle, _p(pd), _p((gr * 2).to(gpu)), _p(buf), 1000, 0.7, 0.9, wd, 1 if k == 0 else 0, 0.5, s), "sgd")
+            assert _rel(pd, pr.detach()) < 1e-6
 
 
 def _engine(golden, gpu, **kw):
