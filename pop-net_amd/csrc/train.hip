@@ -471,6 +471,13 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
         for (int j = 0; j < 8; ++j) cmask |= (unsigned)(cbase + j < c.Cin) << j;
         // ---- halo tile of 32 channels (all loads first, then split + 16-byte stores) ----
         float hv[NH][8];
+#ifdef TX_FAKE_NOHALO                       // timing-only ablation (wrong results): no halo loads
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[i][j] = 1.f;
+        if (0)
+#endif
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
             const int okp = (int)(hoff[i] >= 0);
@@ -526,8 +533,10 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+#ifndef TX_FAKE_ONEPASS                     // timing-only ablation (wrong results): one MFMA pass instead of three
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+#endif
                     }
                 }
             }
