@@ -255,7 +255,9 @@ int pn_rasterize_targets(pn_ctx *ctx, const float *kp2d_dev, const double *kp_z_
  *   pn_bn_train_forward nn.BatchNorm2d in train mode: batch statistics (biased variance, eps), running statistics updated
  *                       with `momentum` (unbiased variance) when given, y = act(bn(x) + res); act = 0 none, 1 ReLU,
  *                       2 LeakyReLU(0.1); res (BasicBlock identity, rtpose_light3d.py:66-67) or NULL
- *   pn_bn_train_backward  gradient of the above: dy is the gradient w.r.t. y, out = y (for the activation mask);
+ *   pn_bn_train_backward  gradient of the above: dy is the gradient w.r.t. y, out = y (for the activation mask) -- or NULL when the
+ *                       forward had no residual input: the mask is then recomputed from x with the forward's own expression
+ *                       (same float operations, same result; one tensor less to read, beta required);
  *                       dres (or NULL) receives / accumulates the gradient of the residual input
  *   pn_avgpool3s2_*     nn.AvgPool2d(3, 2, 1) (rtpose_light3d.py:152,158), planes = N * C
  *   pn_head_forward     s = sigmoid(v); out = kind ? (s - 0.5) * 4 : s (rtpose_light3d.py:335-337) written with an image
@@ -280,7 +282,7 @@ int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev,
                         float *y_dev, float *save_mean_dev, float *save_invstd_dev, float *running_mean_dev,
                         float *running_var_dev, float momentum, float eps, int act, int N, int C, int HW, void *hip_stream);
 int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, const float *out_dev, const float *gamma_dev,
-                         const float *save_mean_dev, const float *save_invstd_dev, int act, int N, int C, int HW, float *dx_dev,
+                         const float *beta_dev, const float *save_mean_dev, const float *save_invstd_dev, int act, int N, int C, int HW, float *dx_dev,
                          float *dgamma_dev, float *dbeta_dev, float *dres_dev, int dres_accumulate, void *hip_stream);
 int pn_avgpool3s2_forward(pn_ctx *ctx, const float *x_dev, float *y_dev, int planes, int H, int W, void *hip_stream);
 int pn_avgpool3s2_backward(pn_ctx *ctx, const float *dy_dev, float *dx_dev, int planes, int H, int W, void *hip_stream);

@@ -110,7 +110,7 @@ _SIGNATURES = {
     "pn_conv2d_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "pn_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "pn_bn_train_forward": (_i, [_vp] * 10 + [_f, _f] + [_i] * 4 + [_vp]),
-    "pn_bn_train_backward": (_i, [_vp] * 7 + [_i] * 4 + [_vp] * 4 + [_i, _vp]),
+    "pn_bn_train_backward": (_i, [_vp] * 8 + [_i] * 4 + [_vp] * 4 + [_i, _vp]),
     "pn_avgpool3s2_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "pn_avgpool3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "pn_head_forward": (_i, [_vp, _vp, _vp, _vp] + [_i] * 4 + [_vp, _vp, _i, _vp, _vp]),

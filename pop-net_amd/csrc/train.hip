@@ -891,30 +891,48 @@ __device__ __forceinline__ double t_block_sum(double v, double *sh) {
 
 // MODE 0: sum x, sum x^2 (BN statistics).  MODE 1: sum g, sum g * (x - mean) with g = dy * act'(out) (BN backward).
 // MODE 2: sum dy (bias gradient).
+// BatchNorm's affine map, ONE definition for the forward and for the mask the backward recomputes from x (explicit fma: the
+// three kernels that evaluate it must round identically)
+__device__ __forceinline__ float t_bn_affine(float x, float mean, float invstd, float gamma, float beta) {
+    return __fmaf_rn((x - mean) * invstd, gamma, beta);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
-                                                           const float *__restrict__ mean, int act, int N, int C, int HW, int slices,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, int act, int N, int C, int HW, int slices,
                                                            double *__restrict__ partial) {
     __shared__ double sh[4];
     const int ch = blockIdx.x, sl = blockIdx.y;
     const long total = (long)N * HW, per = (total + slices - 1) / slices;
     const long beg = sl * per, end = min(beg + per, total);
     const float mu = MODE == 1 ? mean[ch] : 0.f;
+    // out == nullptr (no residual in the forward): the activation mask is recomputed from x with the forward's own expression
+    const bool remask = MODE == 1 && !out && act != PN_ACT_NONE;
+    const float a_s = remask ? invstd[ch] : 0.f, a_g = remask ? gamma[ch] : 0.f, a_b = remask ? beta[ch] : 0.f;
     double s0 = 0.0, s1 = 0.0;
-    for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
-        const long n = i / HW, p = i - n * HW;
+    // (image, pixel) walked without a division per element
+    long i = beg + threadIdx.x;
+    int n = (int)(i / HW), p = (int)(i - (long)n * HW);
+    for (; i < end; i += 256) {
         const size_t off = ((size_t)n * C + ch) * HW + p;
         if (MODE == 0) {
             const double v = x[off];
             s0 += v; s1 += v * v;
         } else if (MODE == 1) {
             float g = dy[off];
-            if (act == PN_ACT_RELU) g = out[off] > 0.f ? g : 0.f;
-            else if (act == PN_ACT_LEAKY) g = out[off] > 0.f ? g : g * 0.1f;
-            s0 += g; s1 += (double)g * (double)(x[off] - mu);
+            const float xv = x[off];
+            if (act != PN_ACT_NONE) {
+                const float o = out ? out[off] : t_bn_affine(xv, mu, a_s, a_g, a_b);
+                if (act == PN_ACT_RELU) g = o > 0.f ? g : 0.f;
+                else g = o > 0.f ? g : g * 0.1f;
+            }
+            s0 += g; s1 += (double)g * (double)(xv - mu);
         } else {
             s0 += dy[off];
         }
+        p += 256;
+        while (p >= HW) { p -= HW; ++n; }
     }
     const double r0 = t_block_sum(s0, sh);
     const double r1 = t_block_sum(s1, sh);
@@ -969,7 +987,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     if (p >= HW) return;
     const int ch = blockIdx.y % C;
     const size_t i = (size_t)blockIdx.y * HW + p;
-    float v = (x[i] - mean[ch]) * invstd[ch] * gamma[ch] + beta[ch];
+    float v = t_bn_affine(x[i], mean[ch], invstd[ch], gamma[ch], beta[ch]);
     if (res) v += res[i];
     if (act == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
     else if (act == PN_ACT_LEAKY) v = v > 0.f ? v : v * 0.1f;
@@ -979,7 +997,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
 // dx = gamma * invstd * (g - sum_g / n - (x - mean) * invstd^2 * sum_gx / n);  dres (+)= g   (identity path of a BasicBlock)
 // grid (ceil(HW / 256), N * C): the channel is uniform per block, no division per element
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
-                                    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
                                     const float *__restrict__ sum_g, const float *__restrict__ sum_gx, int act, int C, int HW, float inv_count,
                                     float *__restrict__ dx, float *__restrict__ dres, int dres_accumulate) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -987,11 +1005,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     const int ch = blockIdx.y % C;
     const size_t i = (size_t)blockIdx.y * HW + p;
     float g = dy[i];
-    if (act == PN_ACT_RELU) g = out[i] > 0.f ? g : 0.f;
-    else if (act == PN_ACT_LEAKY) g = out[i] > 0.f ? g : g * 0.1f;
-    const float is = invstd[ch];
+    const float is = invstd[ch], xv = x[i], mu = mean[ch];
+    if (act != PN_ACT_NONE) {
+        const float o = out ? out[i] : t_bn_affine(xv, mu, is, gamma[ch], beta[ch]);      // the forward's own expression (bn_apply_kernel)
+        if (act == PN_ACT_RELU) g = o > 0.f ? g : 0.f;
+        else g = o > 0.f ? g : g * 0.1f;
+    }
     const float mg = sum_g[ch] * inv_count, k2 = sum_gx[ch] * inv_count * is * is;
-    dx[i] = (g - mg - (x[i] - mean[ch]) * k2) * is * gamma[ch];
+    dx[i] = (g - mg - (xv - mu) * k2) * is * gamma[ch];
     if (dres) dres[i] = dres_accumulate ? dres[i] + g : g;
 }
 
@@ -1271,7 +1292,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
         }
         if (dbias_dev) {
             double *part = (double *)((char *)ws + ((wn * (size_t)(2 * S) * sizeof(float) + 15) & ~(size_t)15));
-            hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl0), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
+            hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl0), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
             hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl0, dbias_dev, nullptr, nullptr);
         }
         PN_HIP_CHECK(ctx, hipGetLastError());
@@ -1298,7 +1319,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, (int)slices);
     if (dbias_dev) {
         double *part = (double *)((char *)ws + ((wn * slices * sizeof(float) + 15) & ~(size_t)15));
-        hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, 0, N, Cout,
+        hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout,
                            c.Ho * c.Wo, csl, part);
         hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl, dbias_dev, nullptr, nullptr);
     }
@@ -1318,7 +1339,7 @@ int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev,
     int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, nullptr, nullptr, nullptr, 0, N, C, HW, sl, (double *)ws);
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, C, HW, sl, (double *)ws);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, (double)cnt, eps, momentum,
                        save_mean_dev, save_invstd_dev, running_mean_dev, running_var_dev);
     if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_forward: N * C out of range");
@@ -1328,24 +1349,24 @@ int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev,
     return PN_OK;
 }
 
-int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, const float *out_dev, const float *gamma_dev, const float *save_mean_dev,
-                         const float *save_invstd_dev, int act, int N, int C, int HW, float *dx_dev, float *dgamma_dev, float *dbeta_dev,
+int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, const float *out_dev, const float *gamma_dev, const float *beta_dev,
+                         const float *save_mean_dev, const float *save_invstd_dev, int act, int N, int C, int HW, float *dx_dev, float *dgamma_dev, float *dbeta_dev,
                          float *dres_dev, int dres_accumulate, void *hip_stream) {
     T_CTX_CHECK("pn_bn_train_backward")
-    if (!x_dev || !dy_dev || !gamma_dev || !save_mean_dev || !save_invstd_dev || !dx_dev || !dgamma_dev || !dbeta_dev || (act != PN_ACT_NONE && !out_dev))
-        return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: bad arguments");
+    if (!x_dev || !dy_dev || !gamma_dev || !save_mean_dev || !save_invstd_dev || !dx_dev || !dgamma_dev || !dbeta_dev || (act != PN_ACT_NONE && !out_dev && !beta_dev))
+        return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: bad arguments (an activation needs out, or beta to recompute its mask)");
     const long cnt = (long)N * HW;
     const int sl = t_slices(cnt, C);
     void *ws = nullptr;
     int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double) + (size_t)C * sizeof(float), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, dy_dev, out_dev, save_mean_dev, act, N, C, HW, sl, (double *)ws);
+    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, dy_dev, out_dev, save_mean_dev, save_invstd_dev, gamma_dev, beta_dev, act, N, C, HW, sl, (double *)ws);
     // d beta = sum g, sum g (x - mean) (raw, into the scratch) and d gamma = that * invstd
     float *sgx = (float *)((char *)ws + (size_t)C * sl * 2 * sizeof(double));
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, save_invstd_dev, dbeta_dev, sgx, dgamma_dev);
     if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: N * C out of range");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, save_mean_dev,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, beta_dev, save_mean_dev,
                        save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;

@@ -130,14 +130,14 @@ class TrainEngine:
         self._check(self.L.pn_bn_train_forward(self.ctx.handle, self._ptr(x), self._ptr(self.p[name + ".weight"]), self._ptr(self.p[name + ".bias"]), self._ptr(res),
                                                self._ptr(y), self._ptr(mean), self._ptr(invstd), self._ptr(self.stats[name + ".running_mean"]),
                                                self._ptr(self.stats[name + ".running_var"]), BN_MOMENTUM, BN_EPS, act, N, Cc, H * W, self._s()), "pn_bn_train_forward")
-        self.A["bn:" + name] = (x, y, mean, invstd, act)
+        self.A["bn:" + name] = (x, y if res is not None else None, mean, invstd, act)      # without a residual the backward recomputes the mask from x
         return y
 
     def _bn_bwd(self, name, dy, dres=None, dres_accumulate=False):
         x, y, mean, invstd, act = self.A["bn:" + name]
         N, Cc, H, W = x.shape
         dx = self._buf("dc:" + name, x.shape)
-        self._check(self.L.pn_bn_train_backward(self.ctx.handle, self._ptr(x), self._ptr(dy), self._ptr(y), self._ptr(self.p[name + ".weight"]), self._ptr(mean),
+        self._check(self.L.pn_bn_train_backward(self.ctx.handle, self._ptr(x), self._ptr(dy), self._ptr(y), self._ptr(self.p[name + ".weight"]), self._ptr(self.p[name + ".bias"]), self._ptr(mean),
                                                 self._ptr(invstd), act, N, Cc, H * W, self._ptr(dx), self._ptr(self.g[name + ".weight"]),
                                                 self._ptr(self.g[name + ".bias"]), self._ptr(dres), 1 if dres_accumulate else 0, self._s()), "pn_bn_train_backward")
         return dx

@@ -118,8 +118,12 @@ def test_bn_train_forward_backward_vs_torch(gpu, act, with_res):
     assert _rel(y, o.detach()) < 1e-5 and _rel(rmd, rm_r) < 1e-6 and _rel(rvd, rv_r) < 1e-6
     dx, dg, db = torch.empty_like(xd), torch.empty(Cc, device=gpu), torch.empty(Cc, device=gpu)
     dres = torch.full_like(xd, 1.0) if with_res else None
-    ctx.check(L.pn_bn_train_backward(ctx.handle, _p(xd), _p(dyd), _p(y), _p(gd), _p(mean), _p(invstd), act, N, Cc, H * W, _p(dx), _p(dg), _p(db), _p(dres), 1, s), "bn bwd")
+    ctx.check(L.pn_bn_train_backward(ctx.handle, _p(xd), _p(dyd), _p(y), _p(gd), _p(bd), _p(mean), _p(invstd), act, N, Cc, H * W, _p(dx), _p(dg), _p(db), _p(dres), 1, s), "bn bwd")
     assert _rel(dx, xr.grad) < 2e-5 and _rel(dg, gr.grad) < 1e-5 and _rel(db, br.grad) < 1e-5
+    if not with_res:                                            # out = NULL: the mask recomputed from x -- the same gradients, bit for bit
+        dx2, dg2, db2 = torch.empty_like(xd), torch.empty(Cc, device=gpu), torch.empty(Cc, device=gpu)
+        ctx.check(L.pn_bn_train_backward(ctx.handle, _p(xd), _p(dyd), None, _p(gd), _p(bd), _p(mean), _p(invstd), act, N, Cc, H * W, _p(dx2), _p(dg2), _p(db2), None, 0, s), "bn bwd")
+        assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
     if with_res:
         assert _rel(dres, rr.grad + 1.0) < 1e-6            # accumulated onto what was there
 
