@@ -653,29 +653,38 @@ __global__ __launch_bounds__(256, 2) void tconv3_wgrad_x3_kernel(TConv c, TTileW
             *reinterpret_cast<unsigned *>(Yh + (wave + 4 * j) * TXW_YP + 4 * sp) = ph.u;
             *reinterpret_cast<unsigned *>(Yl + (wave + 4 * j) * TXW_YP + 4 * sp) = pl.u;
         }
-        {   // halo of channel hk, elements he0 + 8 i: (row, column) advance without a division; groups of 6 loads in flight (a
-            // fully unrolled all-loads-first version -- 36 values + a 64-bit mask -- spilled: 22.9 instead of 17.2 ms per step)
-            int hy = 0, hx = he0;
+        {   // halo of channel hk, element PAIRS (2 e, 2 e + 1), e = he0 + 8 i: one 4-byte LDS store per plane and pair (2-byte stores
+            // of neighbouring lanes into one bank word serialise: 64 % LDS conflict cycles in the first version); HP is even, so a
+            // pair never straddles a halo row; (row, column) advance without a division; 3 pairs = 6 loads in flight (all 36
+            // loads at once spilled: 22.9 instead of 17.2 ms per step)
+            int hy = 0, hx = 2 * he0;
             const int iy0 = y0 - c.pad, ix0 = x0 - c.pad;
-            for (int e0 = he0; e0 < nh; e0 += 48) {
+            while (hx >= g.HP) { hx -= g.HP; ++hy; }
+            for (int e0 = 2 * he0; e0 < nh; e0 += 48) {
                 float hv[6];
                 int okv[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
+                for (int i = 0; i < 3; ++i) {
                     const int iy = iy0 + hy, ix = ix0 + hx;
-                    okv[i] = hk_ok & (int)(e0 + 8 * i < nh) & (int)(hx < g.TW + 2) & (int)(iy >= 0) & (int)(iy < c.H) & (int)(ix >= 0) & (int)(ix < c.W);
-                    hv[i] = xb[(iy * c.W + ix) & -okv[i]];
-                    hx += 8;
-                    if (hx >= g.HP) { hx -= g.HP; ++hy; }
+                    const int rowok = hk_ok & (int)(e0 + 16 * i < nh) & (int)(iy >= 0) & (int)(iy < c.H);
+                    okv[2 * i] = rowok & (int)(hx < g.TW + 2) & (int)(ix >= 0) & (int)(ix < c.W);
+                    okv[2 * i + 1] = rowok & (int)(hx + 1 < g.TW + 2) & (int)(ix + 1 >= 0) & (int)(ix + 1 < c.W);
+                    hv[2 * i] = xb[(iy * c.W + ix) & -okv[2 * i]];
+                    hv[2 * i + 1] = xb[(iy * c.W + ix + 1) & -okv[2 * i + 1]];
+                    hx += 16;
+                    while (hx >= g.HP) { hx -= g.HP; ++hy; }
                 }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int e = e0 + 8 * i;
+                for (int i = 0; i < 3; ++i) {
+                    const int e = e0 + 16 * i;
                     if (e < nh) {
-                        const float v = okv[i] ? hv[i] : 0.f;
-                        const __bf16 h = (__bf16)v;
-                        *reinterpret_cast<__bf16 *>(Xh + hk * g.CHB + 2 * e) = h;
-                        *reinterpret_cast<__bf16 *>(Xl + hk * g.CHB + 2 * e) = (__bf16)(v - (float)h);
+                        const float v0 = okv[2 * i] ? hv[2 * i] : 0.f, v1 = okv[2 * i + 1] ? hv[2 * i + 1] : 0.f;
+                        const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+                        union { __bf16 b[2]; unsigned u; } ph, pl;
+                        ph.b[0] = h0; ph.b[1] = h1;
+                        pl.b[0] = (__bf16)(v0 - (float)h0); pl.b[1] = (__bf16)(v1 - (float)h1);
+                        *reinterpret_cast<unsigned *>(Xh + hk * g.CHB + 2 * e) = ph.u;
+                        *reinterpret_cast<unsigned *>(Xl + hk * g.CHB + 2 * e) = pl.u;
                     }
                 }
             }

@@ -23,7 +23,7 @@ rng = np.random.default_rng(1)
 batch = [torch.from_numpy(a).to(dev) for a in (rng.normal(0, 1, (B, 1, 224, 224)).astype(np.float32), rng.uniform(0, 1, (B, 16, 28, 28)).astype(np.float32),
                                               rng.uniform(-1, 1, (B, 28, 28, 28)).astype(np.float32), rng.uniform(-1.5, 1.5, (B, 15, 28, 28)).astype(np.float32),
                                               (rng.uniform(0, 1, (B, 15, 28, 28)) < 0.2).astype(np.float32))]
-if os.environ.get("TRAIN_GRAPH", "1") != "0":
+if os.environ.get("TRAIN_GRAPH", "1") != "0" and "nograph" not in sys.argv:
     eng.capture(*batch)
 for _ in range(2):
     t = eng.step(*batch)
