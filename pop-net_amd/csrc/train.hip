@@ -9,6 +9,7 @@
 //   SGD with Nesterov momentum                                                                train_rtpose_light3d_kdh3d_mpaug.py:313-316
 // Roofline: the three GEMM-shaped kernels are MFMA-bound (fp32-input matrix peak 157 TFLOP/s), everything else HBM-bound.
 #include <cmath>
+#include <cstdlib>
 #include "pn_internal.h"
 
 typedef float t_f32x4 __attribute__((ext_vector_type(4)));
@@ -569,6 +570,168 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
     }
 }
 
+// Wide variant: 64 couts x 256 pixel slots per block, a wave owns 64 couts x 64 pixels (4 x 4 MFMA tiles): per tap 8 + 8 fragment
+// reads feed 48 MFMAs (the 128-slot kernel above: 8 + 4 for 24) and a block's packed weight slice -- the larger part of its
+// vector-memory bytes -- serves twice the pixels.  LDS images at a 64-byte pitch with the 16-byte segment XOR-swizzled by
+// (row >> 2) & 3: sixteen consecutive rows x one segment cover sixteen different 16-byte bank groups, for the staging stores and
+// for both operands' fragment reads, and two blocks still fit a CU (76 KB).
+#define TXW2_PITCH 64
+#define TXW2_A_BYTES (3 * 64 * TXW2_PITCH)
+__device__ __forceinline__ int t_swz(int row, int seg) { return row * TXW2_PITCH + 16 * (seg ^ ((row >> 2) & 3)); }
+
+__global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile g, const __bf16 *__restrict__ wpx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t_smem8[];
+    unsigned char *As_hi = t_smem8, *As_lo = t_smem8 + TXW2_A_BYTES;
+    unsigned char *Hs_hi = t_smem8 + 2 * TXW2_A_BYTES;
+    unsigned char *Hs_lo = Hs_hi + g.HR * g.HC * TXW2_PITCH;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int b = blockIdx.x, tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
+    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = blockIdx.y * 64;
+    const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nhalo = g.HR * g.HC;
+    int hbp[4], opix[4];                        // halo pixel of the slot's top-left tap, output pixel (or -1)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int sl = 64 * wave + 16 * n + r;
+        const int ry = sl / g.TW, rx = sl - ry * g.TW;
+        const bool ok = ry < g.R && y0 + ry < c.Ho && x0 + rx < c.Wo;
+        hbp[n] = ok ? ry * g.HC + rx : 0;
+        opix[n] = ok ? (y0 + ry) * c.Wo + x0 + rx : -1;
+    }
+    constexpr int NH = 7;                       // halo tiles have at most 400 pixels (t_tile_geometry_x3w)
+    int hoff[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int e = lane + 64 * i;
+        const int hy = e / g.HC, hx = e - hy * g.HC;
+        const int iy = y0 - c.pad + hy, ix = x0 - c.pad + hx;
+        hoff[i] = (e < nhalo && iy >= 0 && iy < c.H && ix >= 0 && ix < c.W) ? iy * c.W + ix : -1;
+    }
+    const float *xb = c.x + (size_t)img * c.Cin * HW;
+    const size_t wplane = (size_t)((c.Cin + 31) / 32) * 9 * c.Cout * 32;
+
+    t_f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < c.Cin; c0 += 32) {
+        const int cbase = c0 + 8 * wave;
+        unsigned cmask = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cmask |= (unsigned)(cbase + j < c.Cin) << j;
+        // halo of 32 channels, in two halves of the pixel range (56 prefetch registers would not fit next to 64 accumulators)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            constexpr int I0[2] = {0, 4}, I1[2] = {4, NH};
+            float hv[4][8];
+#pragma unroll
+            for (int i = I0[half]; i < I1[half]; ++i) {
+                const int okp = (int)(hoff[i] >= 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[i - I0[half]][j] = xb[((cbase + j) * HW + hoff[i]) & -(okp & (int)((cmask >> j) & 1u))];
+            }
+            if (half == 0) __syncthreads();       // the previous chunk's last kernel row has been consumed
+#pragma unroll
+            for (int i = I0[half]; i < I1[half]; ++i) {
+                const int e = lane + 64 * i;
+                if (e < nhalo) {
+                    t_bf16x8 hi, lo;
+                    t_split8(hv[i - I0[half]], hoff[i] >= 0 ? cmask : 0u, hi, lo);
+                    *reinterpret_cast<t_bf16x8 *>(Hs_hi + t_swz(e, wave)) = hi;
+                    *reinterpret_cast<t_bf16x8 *>(Hs_lo + t_swz(e, wave)) = lo;
+                }
+            }
+        }
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            t_u32x4 wv[6];
+            const __bf16 *wrow = wpx + ((size_t)(c0 >> 5) * 9 + ky * 3) * c.Cout * 32;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int piece = t + 256 * j;
+                const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
+                const int ok = (int)(co0 + co < c.Cout);
+                const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
+                wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
+                if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
+            }
+            if (ky) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int piece = t + 256 * j;
+                const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
+                *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + t_swz(kx * 64 + co, seg)) = wv[j];
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int kx = 0; kx < 3; ++kx) {          // not unrolled: with three taps' fragments hoisted the kernel spills (124 B / lane)
+                t_bf16x8 bh[4], bl[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int o = t_swz(hbp[n] + ky * g.HC + kx, q);
+                    bh[n] = *reinterpret_cast<const t_bf16x8 *>(Hs_hi + o);
+                    bl[n] = *reinterpret_cast<const t_bf16x8 *>(Hs_lo + o);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int ao = t_swz(kx * 64 + 16 * m + r, q);
+                    const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8 *>(As_hi + ao);
+                    const t_bf16x8 al = *reinterpret_cast<const t_bf16x8 *>(As_lo + ao);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int pok = (int)(opix[n] >= 0);
+        float *yb = c.y + (size_t)img * c.Cout * HoWo + (opix[n] & -pok);
+        float old[16];
+        if (c.accumulate) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + 16 * m + 4 * q + i;
+                    old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * m + 4 * q + i;
+                float v = acc[m][n][i];
+                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                if (c.accumulate) v += old[4 * m + i];
+                if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
+            }
+    }
+}
+
+static bool t_tile_geometry_x3w(int Ho, int Wo, int N, int Cout, TTile *g) {     // 256-slot tiles; only when they still fill the chip
+    g->tiles_x = (Wo + 63) / 64;
+    g->TW = (Wo + g->tiles_x - 1) / g->tiles_x;
+    g->R = 256 / g->TW;
+    if (g->R > Ho) g->R = Ho;
+    if (g->R < 1) g->R = 1;
+    g->tiles_y = (Ho + g->R - 1) / g->R;
+    g->HC = g->TW + 2;
+    g->HR = g->R + 2;
+    g->NI = 0;
+    g->CHP = 0;
+    const long blocks = (long)N * g->tiles_x * g->tiles_y * ((Cout + 63) / 64);
+    const long slots = (long)g->R * g->TW;
+    if (getenv("POPNET_TRAIN_X3_WIDE")) return g->HR * g->HC <= 400;      // tests: the wide kernel on every shape it can hold
+    return g->HR * g->HC <= 400 && blocks >= 448 && slots >= 192;
+}
+
 static bool t_tile_geometry_x3(int Ho, int Wo, TTile *g) {       // tiles of at most 64 columns: the halo tile stays under 320 pixels
     g->tiles_x = (Wo + 63) / 64;
     g->TW = (Wo + g->tiles_x - 1) / g->tiles_x;
@@ -755,6 +918,7 @@ static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 K
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done = true;
     }
     return PN_OK;
@@ -1190,6 +1354,13 @@ int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const
         TTile gx;
         if (ctx->train_x3 && Cin >= 32 && t_tile_geometry_x3(c.Ho, c.Wo, &gx)) {
             hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cout, Cin, 0);
+            TTile gw2;
+            if (!getenv("POPNET_TRAIN_X3_NARROW") && t_tile_geometry_x3w(c.Ho, c.Wo, N, Cout, &gw2)) {
+                const size_t ldsw2 = (size_t)2 * TXW2_A_BYTES + (size_t)2 * gw2.HR * gw2.HC * TXW2_PITCH;
+                hipLaunchKernelGGL(tconv3_tile_x3w_kernel, dim3((unsigned)(N * gw2.tiles_x * gw2.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), ldsw2, s, c, gw2, (const __bf16 *)ws);
+                PN_HIP_CHECK(ctx, hipGetLastError());
+                return PN_OK;
+            }
             const size_t ldsx = (size_t)2 * TX_A_BYTES + (size_t)2 * gx.HR * gx.HC * TX_PITCH;
             hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), ldsx, s, c, gx, (const __bf16 *)ws);
             PN_HIP_CHECK(ctx, hipGetLastError());
@@ -1232,6 +1403,13 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
         TTile gx;
         if (ctx->train_x3 && Cout >= 32 && t_tile_geometry_x3(H, W, &gx)) {
             hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cin, Cout, 1);
+            TTile gw2;
+            if (!getenv("POPNET_TRAIN_X3_NARROW") && t_tile_geometry_x3w(H, W, N, Cin, &gw2)) {
+                const size_t ldsw2 = (size_t)2 * TXW2_A_BYTES + (size_t)2 * gw2.HR * gw2.HC * TXW2_PITCH;
+                hipLaunchKernelGGL(tconv3_tile_x3w_kernel, dim3((unsigned)(N * gw2.tiles_x * gw2.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), ldsw2, s, c, gw2, (const __bf16 *)ws);
+                PN_HIP_CHECK(ctx, hipGetLastError());
+                return PN_OK;
+            }
             const size_t ldsx = (size_t)2 * TX_A_BYTES + (size_t)2 * gx.HR * gx.HC * TX_PITCH;
             hipLaunchKernelGGL(tconv3_tile_x3_kernel, dim3((unsigned)(N * gx.tiles_x * gx.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), ldsx, s, c, gx, (const __bf16 *)ws);
             PN_HIP_CHECK(ctx, hipGetLastError());

@@ -53,14 +53,16 @@ def _rel(a, b):
     (2, 64, 20, 112, 64, 3, 1, 1),      # 112 columns: two 56-column tiles in bf16x3 mode
     (1, 40, 11, 70, 72, 3, 1, 1),       # ragged everything
 ])
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
-def test_conv_forward_dgrad_wgrad_vs_torch(gpu, shape, prec):
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16x3-wide"])
+def test_conv_forward_dgrad_wgrad_vs_torch(gpu, shape, prec, monkeypatch):
     """bf16x3 (pn_train_set_precision): the 3x3 forward / data gradient on split-bf16 MFMA -- 16 mantissa bits per operand, so
     1e-4 of the tensor norm instead of 1e-5 (measured ~1e-5); every other kernel is the fp32 one in both modes."""
     from popnet_amd import _lib
     N, Cin, H, W, Cout, ks, stride, pad = shape
     L, ctx = _lib.lib(), _lib.Context(0)
-    ctx.check(L.pn_train_set_precision(ctx.handle, _lib.PN_PREC_BF16X3 if prec == "bf16x3" else 0), "precision")
+    if prec == "bf16x3-wide":                # the 256-slot kernel, which the dispatcher only takes for launches of >= 448 blocks
+        monkeypatch.setenv("POPNET_TRAIN_X3_WIDE", "1")
+    ctx.check(L.pn_train_set_precision(ctx.handle, _lib.PN_PREC_BF16X3 if prec != "fp32" else 0), "precision")
     TOL = 1e-5 if prec == "fp32" else 1e-4
     g = torch.Generator().manual_seed(sum(shape))
     x = torch.randn(N, Cin, H, W, generator=g)
