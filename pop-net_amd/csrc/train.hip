@@ -1070,14 +1070,17 @@ __device__ __forceinline__ float t_bn_affine(float x, float mean, float invstd, 
     return __fmaf_rn((x - mean) * invstd, gamma, beta);
 }
 
-template <int MODE>
+// V = 4: four consecutive pixels per thread and 16-byte loads (HW and the slice length multiples of 4); V = 1 otherwise
+template <int MODE, int V>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
                                                            const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, int act, int N, int C, int HW, int slices,
                                                            double *__restrict__ partial) {
     __shared__ double sh[4];
     const int ch = blockIdx.x, sl = blockIdx.y;
-    const long total = (long)N * HW, per = (total + slices - 1) / slices;
+    const long total = (long)N * HW;
+    long per = (total + slices - 1) / slices;
+    per = (per + V - 1) / V * V;
     const long beg = sl * per, end = min(beg + per, total);
     const float mu = MODE == 1 ? mean[ch] : 0.f;
     // out == nullptr (no residual in the forward): the activation mask is recomputed from x with the forward's own expression
@@ -1085,26 +1088,38 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
     const float a_s = remask ? invstd[ch] : 0.f, a_g = remask ? gamma[ch] : 0.f, a_b = remask ? beta[ch] : 0.f;
     double s0 = 0.0, s1 = 0.0;
     // (image, pixel) walked without a division per element
-    long i = beg + threadIdx.x;
+    long i = beg + (long)threadIdx.x * V;
     int n = (int)(i / HW), p = (int)(i - (long)n * HW);
-    for (; i < end; i += 256) {
+    for (; i < end; i += 256 * V) {
         const size_t off = ((size_t)n * C + ch) * HW + p;
-        if (MODE == 0) {
-            const double v = x[off];
-            s0 += v; s1 += v * v;
-        } else if (MODE == 1) {
-            float g = dy[off];
-            const float xv = x[off];
-            if (act != PN_ACT_NONE) {
-                const float o = out ? out[off] : t_bn_affine(xv, mu, a_s, a_g, a_b);
-                if (act == PN_ACT_RELU) g = o > 0.f ? g : 0.f;
-                else g = o > 0.f ? g : g * 0.1f;
-            }
-            s0 += g; s1 += (double)g * (double)(xv - mu);
+        float xv[V], gv[V], ov[V];
+        if (V == 4) {
+            if (MODE != 2) *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + off);
+            if (MODE != 0) *reinterpret_cast<float4 *>(gv) = *reinterpret_cast<const float4 *>(dy + off);
+            if (MODE == 1 && act != PN_ACT_NONE && out) *reinterpret_cast<float4 *>(ov) = *reinterpret_cast<const float4 *>(out + off);
         } else {
-            s0 += dy[off];
+            if (MODE != 2) xv[0] = x[off];
+            if (MODE != 0) gv[0] = dy[off];
+            if (MODE == 1 && act != PN_ACT_NONE && out) ov[0] = out[off];
         }
-        p += 256;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (MODE == 0) {
+                const double v = xv[k];
+                s0 += v; s1 += v * v;
+            } else if (MODE == 1) {
+                float g = gv[k];
+                if (act != PN_ACT_NONE) {
+                    const float o = out ? ov[k] : t_bn_affine(xv[k], mu, a_s, a_g, a_b);
+                    if (act == PN_ACT_RELU) g = o > 0.f ? g : 0.f;
+                    else g = o > 0.f ? g : g * 0.1f;
+                }
+                s0 += g; s1 += (double)g * (double)(xv[k] - mu);
+            } else {
+                s0 += gv[k];
+            }
+        }
+        p += 256 * V;
         while (p >= HW) { p -= HW; ++n; }
     }
     const double r0 = t_block_sum(s0, sh);
@@ -1113,6 +1128,17 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
         partial[((size_t)ch * slices + sl) * 2] = r0;
         partial[((size_t)ch * slices + sl) * 2 + 1] = r1;
     }
+}
+
+// launches the reduction with 16-byte loads when the layout allows it
+template <int MODE>
+static void t_chan_reduce(hipStream_t s, const float *x, const float *dy, const float *out, const float *mean, const float *invstd, const float *gamma,
+                          const float *beta, int act, int N, int C, int HW, int slices, double *partial) {
+    const bool v4 = (HW & 3) == 0 && ((((size_t)x) | ((size_t)dy) | ((size_t)out)) & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL((chan_reduce_kernel<MODE, 4>), dim3((unsigned)C, (unsigned)slices), dim3(256), 0, s, x, dy, out, mean, invstd, gamma, beta, act, N, C, HW, slices, partial);
+    else
+        hipLaunchKernelGGL((chan_reduce_kernel<MODE, 1>), dim3((unsigned)C, (unsigned)slices), dim3(256), 0, s, x, dy, out, mean, invstd, gamma, beta, act, N, C, HW, slices, partial);
 }
 
 __global__ void bn_stats_finish_kernel(const double *__restrict__ partial, int C, int slices, double count, float eps, float momentum,
@@ -1153,40 +1179,80 @@ __global__ void bn_bwd_finish_kernel(const double *__restrict__ partial, int C, 
     dgamma[ch] = (float)(ss * (double)invstd[ch]);
 }
 
+// V = 4: four consecutive pixels per thread as one 16-byte access (HW a multiple of 4: every map of the network); V = 1 otherwise
+template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                                 const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ res, int act,
                                 int C, int HW, float *__restrict__ y) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (p >= HW) return;
     const int ch = blockIdx.y % C;
     const size_t i = (size_t)blockIdx.y * HW + p;
-    float v = t_bn_affine(x[i], mean[ch], invstd[ch], gamma[ch], beta[ch]);
-    if (res) v += res[i];
-    if (act == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
-    else if (act == PN_ACT_LEAKY) v = v > 0.f ? v : v * 0.1f;
-    y[i] = v;
+    const float mu = mean[ch], is = invstd[ch], ga = gamma[ch], be = beta[ch];
+    float xv[V], rv[V], o[V];
+    if (V == 4) {
+        *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + i);
+        if (res) *reinterpret_cast<float4 *>(rv) = *reinterpret_cast<const float4 *>(res + i);
+    } else {
+        xv[0] = x[i];
+        if (res) rv[0] = res[i];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float v = t_bn_affine(xv[k], mu, is, ga, be);
+        if (res) v += rv[k];
+        if (act == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == PN_ACT_LEAKY) v = v > 0.f ? v : v * 0.1f;
+        o[k] = v;
+    }
+    if (V == 4) *reinterpret_cast<float4 *>(y + i) = *reinterpret_cast<const float4 *>(o);
+    else y[i] = o[0];
 }
 
 // dx = gamma * invstd * (g - sum_g / n - (x - mean) * invstd^2 * sum_gx / n);  dres (+)= g   (identity path of a BasicBlock)
-// grid (ceil(HW / 256), N * C): the channel is uniform per block, no division per element
+// grid (ceil(HW / (256 V)), N * C): the channel is uniform per block, no division per element
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
                                     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
                                     const float *__restrict__ sum_g, const float *__restrict__ sum_gx, int act, int C, int HW, float inv_count,
                                     float *__restrict__ dx, float *__restrict__ dres, int dres_accumulate) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (p >= HW) return;
     const int ch = blockIdx.y % C;
     const size_t i = (size_t)blockIdx.y * HW + p;
-    float g = dy[i];
-    const float is = invstd[ch], xv = x[i], mu = mean[ch];
-    if (act != PN_ACT_NONE) {
-        const float o = out ? out[i] : t_bn_affine(xv, mu, is, gamma[ch], beta[ch]);      // the forward's own expression (bn_apply_kernel)
-        if (act == PN_ACT_RELU) g = o > 0.f ? g : 0.f;
-        else g = o > 0.f ? g : g * 0.1f;
-    }
+    const float is = invstd[ch], mu = mean[ch], ga = gamma[ch];
+    const float be = (act != PN_ACT_NONE && !out) ? beta[ch] : 0.f;
     const float mg = sum_g[ch] * inv_count, k2 = sum_gx[ch] * inv_count * is * is;
-    dx[i] = (g - mg - (xv - mu) * k2) * is * gamma[ch];
-    if (dres) dres[i] = dres_accumulate ? dres[i] + g : g;
+    float xv[V], gv[V], ov[V], dv[V], rv[V];
+    if (V == 4) {
+        *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + i);
+        *reinterpret_cast<float4 *>(gv) = *reinterpret_cast<const float4 *>(dy + i);
+        if (act != PN_ACT_NONE && out) *reinterpret_cast<float4 *>(ov) = *reinterpret_cast<const float4 *>(out + i);
+        if (dres && dres_accumulate) *reinterpret_cast<float4 *>(rv) = *reinterpret_cast<const float4 *>(dres + i);
+    } else {
+        xv[0] = x[i];
+        gv[0] = dy[i];
+        if (act != PN_ACT_NONE && out) ov[0] = out[i];
+        if (dres && dres_accumulate) rv[0] = dres[i];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float g = gv[k];
+        if (act != PN_ACT_NONE) {
+            const float o = out ? ov[k] : t_bn_affine(xv[k], mu, is, ga, be);      // the forward's own expression (bn_apply_kernel)
+            if (act == PN_ACT_RELU) g = o > 0.f ? g : 0.f;
+            else g = o > 0.f ? g : g * 0.1f;
+        }
+        dv[k] = (g - mg - (xv[k] - mu) * k2) * is * ga;
+        gv[k] = (dres && dres_accumulate) ? rv[k] + g : g;
+    }
+    if (V == 4) {
+        *reinterpret_cast<float4 *>(dx + i) = *reinterpret_cast<const float4 *>(dv);
+        if (dres) *reinterpret_cast<float4 *>(dres + i) = *reinterpret_cast<const float4 *>(gv);
+    } else {
+        dx[i] = dv[0];
+        if (dres) dres[i] = gv[0];
+    }
 }
 
 // AvgPool2d(3, stride 2, padding 1), count_include_pad = True
@@ -1479,7 +1545,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
         }
         if (dbias_dev) {
             double *part = (double *)((char *)ws + ((wn * (size_t)(2 * S) * sizeof(float) + 15) & ~(size_t)15));
-            hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl0), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
+            t_chan_reduce<2>(s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
             hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl0, dbias_dev, nullptr, nullptr);
         }
         PN_HIP_CHECK(ctx, hipGetLastError());
@@ -1506,8 +1572,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, (int)slices);
     if (dbias_dev) {
         double *part = (double *)((char *)ws + ((wn * slices * sizeof(float) + 15) & ~(size_t)15));
-        hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3((unsigned)Cout, (unsigned)csl), dim3(256), 0, s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout,
-                           c.Ho * c.Wo, csl, part);
+        t_chan_reduce<2>(s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl, part);
         hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl, dbias_dev, nullptr, nullptr);
     }
     PN_HIP_CHECK(ctx, hipGetLastError());
@@ -1526,12 +1591,17 @@ int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev,
     int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, C, HW, sl, (double *)ws);
+    t_chan_reduce<0>(s, x_dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, C, HW, sl, (double *)ws);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, (double)cnt, eps, momentum,
                        save_mean_dev, save_invstd_dev, running_mean_dev, running_var_dev);
     if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_forward: N * C out of range");
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev, save_invstd_dev,
-                       res_dev, act, C, HW, y_dev);
+    const bool v4 = (HW & 3) == 0 && ((((size_t)x_dev) | ((size_t)y_dev) | ((size_t)res_dev)) & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev,
+                           save_invstd_dev, res_dev, act, C, HW, y_dev);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev,
+                           save_invstd_dev, res_dev, act, C, HW, y_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -1548,13 +1618,18 @@ int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, c
     int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double) + (size_t)C * sizeof(float), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3((unsigned)C, (unsigned)sl), dim3(256), 0, s, x_dev, dy_dev, out_dev, save_mean_dev, save_invstd_dev, gamma_dev, beta_dev, act, N, C, HW, sl, (double *)ws);
+    t_chan_reduce<1>(s, x_dev, dy_dev, out_dev, save_mean_dev, save_invstd_dev, gamma_dev, beta_dev, act, N, C, HW, sl, (double *)ws);
     // d beta = sum g, sum g (x - mean) (raw, into the scratch) and d gamma = that * invstd
     float *sgx = (float *)((char *)ws + (size_t)C * sl * 2 * sizeof(double));
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, save_invstd_dev, dbeta_dev, sgx, dgamma_dev);
     if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: N * C out of range");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, beta_dev, save_mean_dev,
-                       save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
+    const bool v4 = (HW & 3) == 0 && ((((size_t)x_dev) | ((size_t)dy_dev) | ((size_t)out_dev) | ((size_t)dx_dev) | ((size_t)dres_dev)) & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, beta_dev,
+                           save_mean_dev, save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, beta_dev,
+                           save_mean_dev, save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }

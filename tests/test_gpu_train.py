@@ -93,11 +93,12 @@ def test_conv_forward_dgrad_wgrad_vs_torch(gpu, shape, prec, monkeypatch):
         assert _rel(dx, 2 * xr.grad) < TOL
 
 
+@pytest.mark.parametrize("hw", [(13, 9), (12, 8)])       # odd map: scalar kernels; H * W a multiple of 4: the 16-byte variants
 @pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (1, True), (2, False)])
-def test_bn_train_forward_backward_vs_torch(gpu, act, with_res):
+def test_bn_train_forward_backward_vs_torch(gpu, act, with_res, hw):
     from popnet_amd import _lib
     L, ctx = _lib.lib(), _lib.Context.for_device(0)
-    N, Cc, H, W = 3, 70, 13, 9
+    N, Cc, (H, W) = 3, 70, hw
     g = torch.Generator().manual_seed(5 + act)
     x = torch.randn(N, Cc, H, W, generator=g) * 2 + 0.5
     gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
