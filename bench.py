@@ -214,7 +214,7 @@ def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=Fal
         extra["bf16x3"] = {k: fast[k] for k in ("ms_per_step", "frames_per_s_per_gpu", "tflops", "loss_first_step", "loss_last_step")}
         extra["bf16x3"]["what"] = "TrainEngine(precision='bf16x3'): the 3x3 convolutions (forward, data and weight gradient) on split-bf16 MFMA, fp32 tensors"
     return {**extra, "ms_per_step": round(dt * 1e3, 3), "frames_per_s_per_gpu": round(BATCH / dt, 1), "tflops": round(flops / dt / 1e12, 1), "dtype": "f32",
-            "peak_tflops_f32_mfma": 157.0, "batch_per_gpu": BATCH, "input": "224x224", "parameters": int(eng.flat_p.numel()),
+            "peak_tflops_f32_mfma": 157.0, "batch_per_gpu": BATCH, "input": "224x224", "parameters": int(eng.n_params),
             "loss_first_step": round(first, 5), "loss_last_step": round(float(t.sum()), 5), "targets_on_gpu_ms_per_batch": round(t_targets * 1e3, 3),
             "launch_mode": "hipGraph replay of the step" if world == 1 else "hipGraph replay of forward + backward, all-reduce and update eager",
             "what": "TrainEngine.step: train-mode forward (batch-statistics BatchNorm), fg-weighted loss, backward (MFMA dgrad / wgrad), Nesterov SGD; %s"

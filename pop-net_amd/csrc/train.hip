@@ -1039,12 +1039,29 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
     }
 }
 
+template <int V>
 __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, int n, int slices) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += partial[(size_t)k * n + i];
-    dw[i] = s;
+    float s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.f;
+    for (int k = 0; k < slices; ++k) {            // slice order: deterministic
+        float p[V];
+        if (V == 4) *reinterpret_cast<float4 *>(p) = *reinterpret_cast<const float4 *>(partial + (size_t)k * n + i);
+        else p[0] = partial[(size_t)k * n + i];
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] += p[v];
+    }
+    if (V == 4) *reinterpret_cast<float4 *>(dw + i) = *reinterpret_cast<const float4 *>(s);
+    else dw[i] = s[0];
+}
+
+static void t_wgrad_reduce(hipStream_t s, const float *partial, float *dw, size_t wn, int slices) {
+    if ((wn & 3) == 0 && ((((size_t)partial) | ((size_t)dw)) & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((wn / 4 + 255) / 256)), dim3(256), 0, s, partial, dw, (int)wn, slices);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, partial, dw, (int)wn, slices);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1534,14 +1551,14 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
             if (S2 <= 2 * S) {                      // the partial buffer was sized for 2 S slices
                 const size_t ldsw = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
                 hipLaunchKernelGGL(tconv3_wgrad_x3_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S2), dim3(256), ldsw, s, c, gw, (float *)ws, tps2, nt);
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S2);
+                t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)S2);
                 done = true;
             }
         }
         if (!done) {
             const size_t lds = (size_t)(128 * TT_YP + g.HR * g.HC * TT_HP + 128) * sizeof(float);
             hipLaunchKernelGGL(tconv3_wgrad_tile_kernel, dim3((unsigned)((Cin + 15) / 16), (unsigned)((Cout + 63) / 64), (unsigned)S), dim3(256), lds, s, c, g, (float *)ws, tps, ntiles);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, S);
+            t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)S);
         }
         if (dbias_dev) {
             double *part = (double *)((char *)ws + ((wn * (size_t)(2 * S) * sizeof(float) + 15) & ~(size_t)15));
@@ -1569,7 +1586,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
     if (ks == 1) hipLaunchKernelGGL(tconv_wgrad_kernel<1>, grid, block, 0, s, c, (float *)ws, (int)pps);
     else if (ks == 3) hipLaunchKernelGGL(tconv_wgrad_kernel<3>, grid, block, 0, s, c, (float *)ws, (int)pps);
     else hipLaunchKernelGGL(tconv_wgrad_kernel<7>, grid, block, 0, s, c, (float *)ws, (int)pps);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, (const float *)ws, dw_dev, (int)wn, (int)slices);
+    t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)slices);
     if (dbias_dev) {
         double *part = (double *)((char *)ws + ((wn * slices * sizeof(float) + 15) & ~(size_t)15));
         t_chan_reduce<2>(s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl, part);

@@ -49,16 +49,21 @@ class TrainEngine:
         self.extra = {k: v.clone() for k, v in sd.items() if k.startswith("model0.layer3")}       # carried, never trained
         names = [k for k in sd if not _is_stat(k) and not k.startswith("model0.layer3")]
         sizes = [sd[k].numel() for k in names]
-        total = sum(sizes)
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=self.device)
+        self.n_params = sum(sizes)
+        # every tensor starts on a 16-byte boundary of the flat buffers (the kernels take their 16-byte paths only on aligned
+        # pointers); the few padding floats are zero in all three buffers and stay zero under SGD and the all-reduce
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) // 4 * 4
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=self.device)
-        self.p, self.g, off = {}, {}, 0
-        for k, n in zip(names, sizes):
+        self.p, self.g = {}, {}
+        for k, n, off in zip(names, sizes, offs):
             self.p[k] = self.flat_p[off:off + n].view(sd[k].shape)
             self.g[k] = self.flat_g[off:off + n].view(sd[k].shape)
             self.p[k].copy_(sd[k].to(torch.float32))
-            off += n
         self.stats = {k: v.to(self.device, torch.float32).clone() for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
         self.tracked = {k: int(v) for k, v in sd.items() if k.endswith("num_batches_tracked")}
         self.steps = 0
