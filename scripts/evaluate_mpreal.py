@@ -12,7 +12,9 @@ import json
 import os
 import sys
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # 3 compute streams + copies: one hardware queue each (see bench.py); before torch loads the runtime
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
