@@ -897,6 +897,167 @@ __global__ __launch_bounds__(256, 2) void tconv3_wgrad_x3_kernel(TConv c, TTileW
     }
 }
 
+__global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3pp_kernel(TConv c, TTileW g, float *__restrict__ partial, int tiles_per_slice, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t_smem8[];
+    // two wave groups of 256 threads, each with its own LDS image set; in phase p group (p & 1) stages tile p while the other
+    // group runs the MFMAs of tile p - 1: ONE block barrier per phase, staging and matrix work always overlap inside the block,
+    // and the block writes ONE partial tile (the groups' accumulators are added through LDS): half the partial-sum traffic of
+    // two independent 4-wave blocks per CU
+    const int set_bytes = 2 * 64 * TXW_YP + 2 * TXW_CI * g.CHB;
+    const int grp = threadIdx.x >> 8;
+    unsigned char *sbase = t_smem8 + grp * set_bytes;
+    unsigned char *Yh = sbase, *Yl = sbase + 64 * TXW_YP;                       // dY tile [64 couts][128 slots]
+    unsigned char *Xh = sbase + 2 * 64 * TXW_YP, *Xl = Xh + TXW_CI * g.CHB;     // halo [32 channels][HR][HP]
+    const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int c0 = blockIdx.x * TXW_CI, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nh = g.HR * g.HP;
+    int hbq[4];                                   // byte offset (inside a channel's halo) of this lane's 8-slot group, per pixel group
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+        const int s0 = 32 * pg + 8 * q, ry = s0 / g.SW, rx0 = s0 - ry * g.SW;
+        hbq[pg] = (ry < g.R ? ry * g.HP + rx0 : 0) * 2;
+    }
+    // staging roles: dY -- slot pair (2 sp, 2 sp + 1), couts wave + 4 j;  halo -- channel t >> 3, elements (t & 7) + 8 i
+    const int sp = t & 63, s_a = 2 * sp, ry_a = s_a / g.SW, rx_a = s_a - ry_a * g.SW;
+    const int hk = t >> 3, he0 = t & 7;
+    const int hk_ok = (int)(c0 + hk < c.Cin);
+    t_f32x4 acc[2][9];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[n][k] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tbeg = slice * tiles_per_slice, tend = min(tbeg + tiles_per_slice, ntiles), ntl = tend - tbeg;
+    for (int ph = 0; ph <= ntl; ++ph) {
+      if ((ph & 1) == grp) {
+        if (ph < ntl) {
+        const int tile = tbeg + ph;
+        const int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, img = tile / (g.tiles_x * g.tiles_y);
+        const int y0 = ty * g.R, x0 = tx * g.TW;
+        const bool rowok = ry_a < g.R && y0 + ry_a < c.Ho;
+        const int ok0 = (int)(rowok && rx_a < g.TW && x0 + rx_a < c.Wo), ok1 = (int)(rowok && rx_a + 1 < g.TW && x0 + rx_a + 1 < c.Wo);
+        const float *dyb = c.y + (size_t)img * c.Cout * HoWo + (rowok ? (y0 + ry_a) * c.Wo + x0 + rx_a : 0);
+        const float *xb = c.x + (size_t)img * c.Cin * HW + (size_t)(hk_ok ? c0 + hk : 0) * HW;
+        float d0[16], d1[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + wave + 4 * j;
+            const int cok = (int)(co < c.Cout);
+            d0[j] = dyb[(co * HoWo) & -(ok0 & cok)];
+            d1[j] = dyb[(co * HoWo + 1) & -(ok1 & cok)];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + wave + 4 * j;
+            const float v0 = (ok0 && co < c.Cout) ? d0[j] : 0.f, v1 = (ok1 && co < c.Cout) ? d1[j] : 0.f;
+            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+            union { __bf16 b[2]; unsigned u; } ph, pl;
+            ph.b[0] = h0; ph.b[1] = h1; pl.b[0] = l0; pl.b[1] = l1;
+            *reinterpret_cast<unsigned *>(Yh + (wave + 4 * j) * TXW_YP + 4 * sp) = ph.u;
+            *reinterpret_cast<unsigned *>(Yl + (wave + 4 * j) * TXW_YP + 4 * sp) = pl.u;
+        }
+        {   // halo of channel hk, element PAIRS (2 e, 2 e + 1), e = he0 + 8 i: one 4-byte LDS store per plane and pair (2-byte stores
+            // of neighbouring lanes into one bank word serialise: 64 % LDS conflict cycles in the first version); HP is even, so a
+            // pair never straddles a halo row; (row, column) advance without a division; 3 pairs = 6 loads in flight (all 36
+            // loads at once spilled: 22.9 instead of 17.2 ms per step)
+            int hy = 0, hx = 2 * he0;
+            const int iy0 = y0 - c.pad, ix0 = x0 - c.pad;
+            while (hx >= g.HP) { hx -= g.HP; ++hy; }
+            for (int e0 = 2 * he0; e0 < nh; e0 += 48) {
+                float hv[6];
+                int okv[6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int iy = iy0 + hy, ix = ix0 + hx;
+                    const int rowok = hk_ok & (int)(e0 + 16 * i < nh) & (int)(iy >= 0) & (int)(iy < c.H);
+                    okv[2 * i] = rowok & (int)(hx < g.TW + 2) & (int)(ix >= 0) & (int)(ix < c.W);
+                    okv[2 * i + 1] = rowok & (int)(hx + 1 < g.TW + 2) & (int)(ix + 1 >= 0) & (int)(ix + 1 < c.W);
+                    hv[2 * i] = xb[(iy * c.W + ix) & -okv[2 * i]];
+                    hv[2 * i + 1] = xb[(iy * c.W + ix + 1) & -okv[2 * i + 1]];
+                    hx += 16;
+                    while (hx >= g.HP) { hx -= g.HP; ++hy; }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int e = e0 + 16 * i;
+                    if (e < nh) {
+                        const float v0 = okv[2 * i] ? hv[2 * i] : 0.f, v1 = okv[2 * i + 1] ? hv[2 * i + 1] : 0.f;
+                        const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+                        union { __bf16 b[2]; unsigned u; } ph, pl;
+                        ph.b[0] = h0; ph.b[1] = h1;
+                        pl.b[0] = (__bf16)(v0 - (float)h0); pl.b[1] = (__bf16)(v1 - (float)h1);
+                        *reinterpret_cast<unsigned *>(Xh + hk * g.CHB + 2 * e) = ph.u;
+                        *reinterpret_cast<unsigned *>(Xl + hk * g.CHB + 2 * e) = pl.u;
+                    }
+                }
+            }
+        }
+        }
+      } else if (ph >= 1) {
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+            const int ao = (16 * wave + r) * TXW_YP + 64 * pg + 16 * q;
+            const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8 *>(Yh + ao), al = *reinterpret_cast<const t_bf16x8 *>(Yl + ao);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int bo = (16 * n + r) * g.CHB + hbq[pg] + ky * g.HP * 2;
+                    const t_u32x4 vh = *reinterpret_cast<const t_u32x4 *>(Xh + bo), vl = *reinterpret_cast<const t_u32x4 *>(Xl + bo);
+                    const unsigned nh4 = *reinterpret_cast<const unsigned *>(Xh + bo + 16), nl4 = *reinterpret_cast<const unsigned *>(Xl + bo + 16);
+                    t_bf16x8 bh[3], bl[3];
+                    bh[0] = t_as_bf16x8(vh);
+                    bl[0] = t_as_bf16x8(vl);
+                    bh[1] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vh[1], vh[0], 2), __builtin_amdgcn_alignbyte(vh[2], vh[1], 2),
+                                                __builtin_amdgcn_alignbyte(vh[3], vh[2], 2), __builtin_amdgcn_alignbyte(nh4, vh[3], 2)});
+                    bl[1] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vl[1], vl[0], 2), __builtin_amdgcn_alignbyte(vl[2], vl[1], 2),
+                                                __builtin_amdgcn_alignbyte(vl[3], vl[2], 2), __builtin_amdgcn_alignbyte(nl4, vl[3], 2)});
+                    bh[2] = t_as_bf16x8(t_u32x4{vh[1], vh[2], vh[3], nh4});
+                    bl[2] = t_as_bf16x8(t_u32x4{vl[1], vl[2], vl[3], nl4});
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+        }
+      }
+      __syncthreads();
+    }
+    // add the two groups' accumulators through LDS (72 floats per thread, the image sets are free now)
+    float *scr = reinterpret_cast<float *>(t_smem8);
+    if (grp == 1) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int k9 = 0; k9 < 9; ++k9)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) scr[((n * 9 + k9) * 4 + i) * 256 + t] = acc[n][k9][i];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int k9 = 0; k9 < 9; ++k9)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[n][k9][i] += scr[((n * 9 + k9) * 4 + i) * 256 + t];
+    float *pb = partial + (size_t)slice * c.Cout * c.Kdim;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int ci = c0 + 16 * n + r;
+        if (ci >= c.Cin) continue;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * wave + 4 * q + i;
+                if (co < c.Cout) pb[((size_t)co * c.Cin + ci) * 9 + tap] = acc[n][tap][i];
+            }
+    }
+}
+
 static bool t_tile_geometry_wx3(int Ho, int Wo, TTileW *g) {
     g->tiles_x = (Wo + 63) / 64;
     g->TW = (Wo + g->tiles_x - 1) / g->tiles_x;
@@ -919,6 +1080,7 @@ static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 K
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_x3pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done = true;
     }
     return PN_OK;
@@ -1548,7 +1710,16 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
             if (S2 < 1) S2 = 1;
             const int tps2 = (nt + S2 - 1) / S2;
             S2 = (nt + tps2 - 1) / tps2;
-            if (S2 <= 2 * S) {                      // the partial buffer was sized for 2 S slices
+            const size_t setb = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
+            int S3 = (256 + groups2 - 1) / groups2;         // ping-pong variant: one 8-wave block per CU
+            if (S3 > nt / 2) S3 = nt / 2;                   // at least two tiles per block, or the second wave group has nothing to do
+            if (!getenv("POPNET_TRAIN_WGRAD_4WAVE") && S3 >= 1 && 2 * setb <= 158 * 1024 && 2 * setb >= 73728) {
+                const int tps3 = (nt + S3 - 1) / S3;
+                S3 = (nt + tps3 - 1) / tps3;
+                hipLaunchKernelGGL(tconv3_wgrad_x3pp_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S3), dim3(512), 2 * setb, s, c, gw, (float *)ws, tps3, nt);
+                t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, S3);
+                done = true;
+            } else if (S2 <= 2 * S) {               // the partial buffer was sized for 2 S slices
                 const size_t ldsw = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
                 hipLaunchKernelGGL(tconv3_wgrad_x3_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S2), dim3(256), ldsw, s, c, gw, (float *)ws, tps2, nt);
                 t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)S2);
