@@ -3,7 +3,7 @@
 Everything under ``oracle/`` is a CPU restatement of the reference algorithm
 (``/root/reference``; citations in each function) used to CHECK the HIP path.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
-leg may import it.  The product package (``pop-net_amd/`` == ``popnet_amd``)
+leg may import it.  The product package (``popnet_amd/`` == ``popnet_amd``)
 never does: it fails loudly when the HIP library is missing.
 
 Pinning status (see DESIGN.md "Oracle"):

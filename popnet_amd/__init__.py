@@ -1,7 +1,7 @@
 """popnet_amd -- MI355X-native PoP-Net / MP-3DHP inference path.
 
-The directory is named ``pop-net_amd`` (not importable as such); ``popnet_amd.py`` at the repo
-root maps it to the importable package name ``popnet_amd``.
+``pop-net_amd`` at the repo root is a symlink to this directory (the layout name of the build
+contract); import the package as ``popnet_amd``.
 
 Public surface = the reference's own names for this path:
     popnet_amd.network.rtpose_light3d.rtpose_light3d      tpm/lib/network/rtpose_light3d.py:249

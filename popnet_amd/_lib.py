@@ -1,7 +1,7 @@
 """ctypes binding of libpopnet_hip.so (the C ABI declared in include/popnet_hip.h).
 
 There is NO fallback: if the HIP library is missing or fails to load, importing any compute entry
-point of this package raises.  The library is built in-tree by ``pop-net_amd/build.py`` (or
+point of this package raises.  The library is built in-tree by ``popnet_amd/build.py`` (or
 ``__graft_entry__.build()``).
 """
 import ctypes as C
@@ -142,7 +142,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise PopnetError(
             "popnet_amd: %s not found -- the HIP extension is required (no CPU fallback). "
-            "Build it with `python pop-net_amd/build.py`." % LIB_PATH)
+            "Build it with `python popnet_amd/build.py`." % LIB_PATH)
     try:
         handle = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -1,7 +1,7 @@
-"""Builds libpopnet_hip.so (gfx950) in-tree from pop-net_amd/csrc/*.hip with hipcc.
+"""Builds libpopnet_hip.so (gfx950) in-tree from popnet_amd/csrc/*.hip with hipcc.
 
 hipcc cross-compiles without a GPU; one object per translation unit, compiled in parallel.
-Usage:  python pop-net_amd/build.py [--force]
+Usage:  python popnet_amd/build.py [--force]
 """
 import os
 import subprocess

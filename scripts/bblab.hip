@@ -1,6 +1,6 @@
 // Development tool: times bb64_kernel (fused BasicBlock(64)) on synthetic data; -DPN_STAMP dumps an in-kernel timeline
 // of the third tile of every workgroup (stamps: 1 tile start, 2 conv1 done, 3 intermediate written, 4 conv2 done, 5 tile end).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipop-net_amd/csrc scripts/bblab.hip -o pop-net_amd/build/bblab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipopnet_amd/csrc scripts/bblab.hip -o popnet_amd/build/bblab
 //   bblab B H W [iters]
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -1,6 +1,6 @@
 # In-kernel shader clock under the conv kernels and the matrix-core ceiling of this box (scripts/mfma_peak.hip,
 # scripts/convlab.hip built with -DPN_STAMP); run from the repo root on the GPU box.
-cd pop-net_amd/build
+cd popnet_amd/build
 for w in 4 2 1; do timeout 60 ./mfma_peak $w 2 1; done
 timeout 60 ./mfma_peak 4 2 0
 export NBUF=1

@@ -1,6 +1,6 @@
 // Development tool (not part of the product): times ONE launch of conv4_kernel (optionally a level of several
 // convolutions, GROUP="cin:cout,...") on synthetic data and checks the first problem against a naive GPU convolution.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipop-net_amd/csrc scripts/conv4lab.hip -o pop-net_amd/build/conv4lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipopnet_amd/csrc scripts/conv4lab.hip -o popnet_amd/build/conv4lab
 //   conv4lab B H W Cin Cout [iters] [res]          (-DPN_STAMP: in-kernel s_memtime timeline, -DLAB_V3: conv3_kernel<3,4,1,1> instead)
 #include <hip/hip_runtime.h>
 #include <math.h>

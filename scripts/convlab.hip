@@ -1,7 +1,7 @@
 // Development tool (not part of the product): times ONE convolution launch of the library's MFMA
 // kernels on synthetic data, checks it against a naive GPU convolution, and (built with -DPN_STAMP)
 // dumps an in-kernel s_memtime timeline per block.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipop-net_amd/csrc scripts/convlab.hip -o pop-net_amd/build/convlab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipopnet_amd/csrc scripts/convlab.hip -o popnet_amd/build/convlab
 //   convlab B H W Cin Cout ks cfg [iters] [kernel]
 #include <hip/hip_runtime.h>
 #include <math.h>

@@ -1,5 +1,5 @@
 #!/bin/bash
-L=pop-net_amd/build
+L=popnet_amd/build
 for q in 3 6 9; do
   echo "== BQ $q"
   $L/conv4lab_bq$q 32 28 28 256 256 1000 | grep -v "mismatch"

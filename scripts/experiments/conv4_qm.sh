@@ -1,6 +1,6 @@
 #!/bin/bash
 # quarter-major (conflict-free) vs half-major B images in conv4_kernel: conv4lab_qm vs conv4lab_bq6 (previous build)
-L=pop-net_amd/build
+L=popnet_amd/build
 for b in conv4lab_bq6 conv4lab_qm; do
   echo "== $b"
   $L/$b 32 28 28 256 256 1000 | grep -v "mismatch"

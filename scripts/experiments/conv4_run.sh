@@ -1,6 +1,6 @@
 #!/bin/bash
 # conv4_kernel vs conv3_kernel on the stage-level shapes (run from the repo root on the GPU box)
-L=pop-net_amd/build
+L=popnet_amd/build
 for shape in "32 28 28 256 256" "32 28 28 128 128" "32 28 28 192 256" "32 56 56 128 128" "3 28 28 128 128" "1 30 26 128 64" "32 28 28 128 256"; do
   $L/conv4lab $shape 200 2>&1 | grep -v mismatch
   $L/conv3lab $shape 200 2>&1 | grep -v mismatch

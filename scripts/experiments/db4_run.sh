@@ -1,4 +1,4 @@
-cd pop-net_amd/build
+cd popnet_amd/build
 export NBUF=1
 for r in 1 2; do for b in convlab convlab_db4; do
   printf "%-12s level  " $b; GROUP="128:128,128:64" timeout 60 ./$b 32 28 28 256 256 3 0 2000 v3 0 | grep "us/launch"

@@ -1,4 +1,4 @@
-cd pop-net_amd/build
+cd popnet_amd/build
 export NBUF=1
 echo "== PT=7 reference"
 GROUP="128:128,128:64" timeout 60 ./convlab 32 28 28 256 256 3 0 2000 v3 0 | grep "us/launch\|check"

@@ -1,4 +1,4 @@
-cd pop-net_amd/build
+cd popnet_amd/build
 export NBUF=1
 printf "PT7  2x2 112res "; timeout 60 ./convlab 32 112 112 64 64 3 1 2000 v3 1 | grep "us/launch"
 printf "PT7  2x2 112    "; timeout 60 ./convlab 32 112 112 64 64 3 1 2000 v3 0 | grep "us/launch"

@@ -1,4 +1,4 @@
-cd pop-net_amd/build
+cd popnet_amd/build
 export NBUF=1
 for r in 1 2; do for b in convlab_prev convlab; do
   printf "%-13s 112res " $b; timeout 60 ./$b 32 112 112 64 64 3 1 2000 v3 1 | grep "us/launch"

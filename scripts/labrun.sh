@@ -1,6 +1,6 @@
 # conv3_kernel timeline stamps and timing-only ablations (scripts/convlab.hip); run from the repo root on the GPU box.
-# Binaries: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHAVE_CONV3 [-DPN_STAMP] [-DPN_CONV3_FAKE_{NOA,NOB,SAMEA,LINDMA,NOWRAP}] -Ipop-net_amd/csrc scripts/convlab.hip
-cd pop-net_amd/build
+# Binaries: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHAVE_CONV3 [-DPN_STAMP] [-DPN_CONV3_FAKE_{NOA,NOB,SAMEA,LINDMA,NOWRAP}] -Ipopnet_amd/csrc scripts/convlab.hip
+cd popnet_amd/build
 export NBUF=1
 echo "== level: 256->256 + 128->128 + 128->64 (3x3, 28x28, B=32) in one launch, conv3_kernel<3,4,1,1>"
 for b in convlab convlab_NOA convlab_SAMEA convlab_NOB convlab_NOAB convlab_LINDMA convlab_nowrap; do

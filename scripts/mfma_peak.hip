@@ -1,6 +1,6 @@
 // What the matrix cores of THIS box sustain on v_mfma_f32_16x16x32_bf16 with nothing else in the loop: the ceiling
 // that profiles/README.md sets the conv kernels' TFLOP/s against, next to the 2.5 PFLOP/s spec figure the bench prices with.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/mfma_peak.hip -o pop-net_amd/build/mfma_peak
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/mfma_peak.hip -o popnet_amd/build/mfma_peak
 //   ./mfma_peak [waves per SIMD = 4] [seconds = 2] [random = 1]
 // Operands are random bf16 in [-1, 1) (or zeros with random = 0: the chip holds a higher clock on zeros); 14 independent
 // accumulator tiles per wave (the conv kernel's 2 x 7), no memory traffic inside the loop.

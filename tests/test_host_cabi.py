@@ -108,7 +108,7 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 def test_product_package_never_imports_the_oracle():
-    pkg = os.path.join(ROOT, "pop-net_amd")
+    pkg = os.path.join(ROOT, "popnet_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
