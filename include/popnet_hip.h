@@ -272,6 +272,9 @@ int pn_rasterize_targets(pn_ctx *ctx, const float *kp2d_dev, const double *kp_z_
  *                       (16 mantissa bits) and run three v_mfma_f32_16x16x32_bf16 per product block -- fp32 tensors in and
  *                       out, results within ~1e-5 relative of the fp32 kernels, 5.3x less matrix-pipe time */
 int pn_train_set_precision(pn_ctx *ctx, int precision);
+/* keep != 0: a hipGraph captured from the training primitives points into the context's scratch; from now on a call that
+ * needs a larger scratch retires the old block (freed by pn_destroy) instead of freeing it, so the graph stays replayable. */
+int pn_train_ws_keep(pn_ctx *ctx, int keep);
 int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const float *bias_dev, float *y_dev, int N, int Cin,
                       int H, int W, int Cout, int ks, int stride, int pad, int accumulate, void *hip_stream);
 int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float *dx_dev, int N, int Cin, int H, int W, int Cout,

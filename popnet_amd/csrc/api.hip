@@ -80,6 +80,7 @@ void pn_destroy(pn_ctx *ctx) {
     if (!ctx) return;
     if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
     if (ctx->train_ws) (void)hipFree(ctx->train_ws);
+    for (void *p : ctx->train_ws_retired) (void)hipFree(p);
     delete ctx;
 }
 

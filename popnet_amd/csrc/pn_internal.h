@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "../../include/popnet_hip.h"
 
 struct pn_ctx {
@@ -16,6 +17,8 @@ struct pn_ctx {
     // scratch of the training kernels (flipped weights, split-reduction partials; train.hip), stream-ordered reuse
     void *train_ws = nullptr;
     size_t train_ws_bytes = 0;
+    bool train_ws_keep = false;      // pn_train_ws_keep: a captured graph points into train_ws -- a growth retires the old block instead of freeing it
+    std::vector<void *> train_ws_retired;
     bool train_lds_attr = false;     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the tile kernels on this device
     bool train_x3 = false;           // pn_train_set_precision: 3x3 forward / data-gradient convolutions on split-bf16 MFMA
 };

@@ -1535,8 +1535,14 @@ __global__ void slice_copy_kernel(const float *__restrict__ src, int src_ld, flo
 static int t_ws(pn_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->train_ws_bytes) {
         if (ctx->train_ws) {
-            PN_HIP_CHECK(ctx, hipDeviceSynchronize());
-            (void)hipFree(ctx->train_ws);
+            if (ctx->train_ws_keep) {
+                // pn_train_ws_keep: a captured hipGraph still points into the old block -- retire it (freed with the ctx)
+                // instead of freeing it; the graph keeps replaying on the old block, eager calls use the new one
+                ctx->train_ws_retired.push_back(ctx->train_ws);
+            } else {
+                PN_HIP_CHECK(ctx, hipDeviceSynchronize());
+                (void)hipFree(ctx->train_ws);
+            }
             ctx->train_ws = nullptr;
             ctx->train_ws_bytes = 0;
         }
@@ -1562,6 +1568,12 @@ static int t_slices(long total, int C) {       // slices per channel so that the
     if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
 
 extern "C" {
+
+int pn_train_ws_keep(pn_ctx *ctx, int keep) {
+    T_CTX_CHECK("pn_train_ws_keep")
+    ctx->train_ws_keep = keep != 0;
+    return PN_OK;
+}
 
 int pn_train_set_precision(pn_ctx *ctx, int precision) {
     T_CTX_CHECK("pn_train_set_precision")
@@ -1695,36 +1707,47 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
         const int tps = (ntiles + S - 1) / S;
         S = (ntiles + tps - 1) / tps;
         const size_t wn = (size_t)Cout * c.Kdim;
+        // slice counts of the split-bf16 variants (their own tile grid): the partial-sum buffer is sized for the largest
+        // grid any of the three kernels may be launched with
+        TTileW gw;
+        const bool x3 = ctx->train_x3 && t_tile_geometry_wx3(c.Ho, c.Wo, &gw);
+        int S2 = 0, S3 = 0, tps2 = 0, tps3 = 0, nt = 0;
+        size_t setb = 0;
+        bool pp = false;
+        if (x3) {
+            nt = N * gw.tiles_x * gw.tiles_y;
+            const int groups2 = ((Cin + TXW_CI - 1) / TXW_CI) * ((Cout + 63) / 64);
+            S2 = (512 + groups2 - 1) / groups2;             // two blocks per CU: 512 fill the chip; fewer slices = less partial-sum traffic
+            if (S2 > nt) S2 = nt;
+            if (S2 < 1) S2 = 1;
+            tps2 = (nt + S2 - 1) / S2;
+            S2 = (nt + tps2 - 1) / tps2;
+            setb = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
+            S3 = (256 + groups2 - 1) / groups2;             // ping-pong variant: one 8-wave block per CU
+            if (S3 > nt / 2) S3 = nt / 2;                   // at least two tiles per block, or the second wave group has nothing to do
+            pp = !getenv("POPNET_TRAIN_WGRAD_4WAVE") && S3 >= 1 && 2 * setb <= 158 * 1024 && 2 * setb >= 73728;
+            if (pp) {
+                tps3 = (nt + S3 - 1) / S3;
+                S3 = (nt + tps3 - 1) / tps3;
+            }
+        }
+        const int Smax = std::max(S, x3 ? (pp ? S3 : S2) : 0);
+        const size_t part_off = (wn * (size_t)Smax * sizeof(float) + 15) & ~(size_t)15;
         void *ws = nullptr;
-        int rc = t_ws(ctx, wn * (size_t)(2 * S) * sizeof(float) + 16 + (size_t)Cout * csl0 * 2 * sizeof(double), &ws);   // 2 S: the split-bf16 grid has half the channel groups
+        int rc = t_ws(ctx, part_off + 16 + (size_t)Cout * csl0 * 2 * sizeof(double), &ws);
         if (rc != PN_OK) return rc;
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
         hipStream_t s = (hipStream_t)hip_stream;
-        TTileW gw;
         bool done = false;
-        if (ctx->train_x3 && t_tile_geometry_wx3(c.Ho, c.Wo, &gw)) {
-            // split-bf16 variant on its own tile grid (same slicing rule)
-            const int nt = N * gw.tiles_x * gw.tiles_y, groups2 = ((Cin + TXW_CI - 1) / TXW_CI) * ((Cout + 63) / 64);
-            int S2 = (512 + groups2 - 1) / groups2;         // two blocks per CU: 512 fill the chip; fewer slices = less partial-sum traffic
-            if (S2 > nt) S2 = nt;
-            if (S2 < 1) S2 = 1;
-            const int tps2 = (nt + S2 - 1) / S2;
-            S2 = (nt + tps2 - 1) / tps2;
-            const size_t setb = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
-            int S3 = (256 + groups2 - 1) / groups2;         // ping-pong variant: one 8-wave block per CU
-            if (S3 > nt / 2) S3 = nt / 2;                   // at least two tiles per block, or the second wave group has nothing to do
-            if (!getenv("POPNET_TRAIN_WGRAD_4WAVE") && S3 >= 1 && 2 * setb <= 158 * 1024 && 2 * setb >= 73728) {
-                const int tps3 = (nt + S3 - 1) / S3;
-                S3 = (nt + tps3 - 1) / tps3;
+        if (x3) {
+            if (pp) {
                 hipLaunchKernelGGL(tconv3_wgrad_x3pp_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S3), dim3(512), 2 * setb, s, c, gw, (float *)ws, tps3, nt);
                 t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, S3);
-                done = true;
-            } else if (S2 <= 2 * S) {               // the partial buffer was sized for 2 S slices
-                const size_t ldsw = (size_t)2 * 64 * TXW_YP + (size_t)2 * TXW_CI * gw.CHB;
-                hipLaunchKernelGGL(tconv3_wgrad_x3_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S2), dim3(256), ldsw, s, c, gw, (float *)ws, tps2, nt);
+            } else {
+                hipLaunchKernelGGL(tconv3_wgrad_x3_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S2), dim3(256), setb, s, c, gw, (float *)ws, tps2, nt);
                 t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)S2);
-                done = true;
             }
+            done = true;
         }
         if (!done) {
             const size_t lds = (size_t)(128 * TT_YP + g.HR * g.HC * TT_HP + 128) * sizeof(float);
@@ -1732,7 +1755,7 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
             t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)S);
         }
         if (dbias_dev) {
-            double *part = (double *)((char *)ws + ((wn * (size_t)(2 * S) * sizeof(float) + 15) & ~(size_t)15));
+            double *part = (double *)((char *)ws + part_off);
             t_chan_reduce<2>(s, nullptr, dy_dev, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, Cout, c.Ho * c.Wo, csl0, part);
             hipLaunchKernelGGL(sums_finish_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(64), 0, s, (const double *)part, Cout, csl0, dbias_dev, nullptr, nullptr);
         }

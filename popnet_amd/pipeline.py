@@ -18,6 +18,7 @@ import torch
 
 from . import _lib, synth
 from .config import DEPTH_MAX, DEPTH_MEAN, DEPTH_STD, INTRINSICS, default_cfg
+from .network._hipnet import _PREC
 from .network.rtpose_light3d import rtpose_light3d
 from .utils.paf_to_pose import make_parse_cfg
 
@@ -44,8 +45,13 @@ class PoseEngine:
         self.L = _lib.lib()
         self.cfg = make_parse_cfg(default_cfg(), input_size=self.S, w_org=w_org, h_org=h_org, intrinsics=intrinsics,
                                   depth_mean=DEPTH_MEAN, depth_std=DEPTH_STD)
-        # the parse scratch is sized once for max_batch: the launch path never reallocates (a captured graph keeps the pointer)
-        self.ctx.check(self.L.pn_parse_reserve(self.ctx.handle, self.max_batch), "pn_parse_reserve")
+        # a PRIVATE context's parse scratch is sized once for max_batch and never moves again (a captured graph keeps the
+        # pointer).  The shared per-device context keeps growing on demand: fixing it here would make an unrelated later
+        # call with a larger batch (utils.paf_to_pose.parse_paf_batch) fail depending on construction order
+        self.private_ctx = bool(private_ctx)
+        if self.private_ctx:
+            self.ctx.check(self.L.pn_parse_reserve(self.ctx.handle, self.max_batch), "pn_parse_reserve")
+        self._locked = False
         h = self.S // 8
         d, f32 = self.device, torch.float32
         self.x = torch.empty((self.max_batch, 1, self.S, self.S), device=d, dtype=f32)
@@ -59,15 +65,22 @@ class PoseEngine:
     def net(self):
         """The model's CURRENT pn_net handle.  The module destroys its handle on invalidate() / load_state_dict() / a
         forward at another size or precision, so the engine never keeps a raw copy: it re-reads (or re-compiles) here."""
-        cached = self.model._net
-        if cached is None or cached[2] < self.max_batch:
-            return self.model._compile(self.device, self.max_batch, self.S, self.S)
-        return cached[0]
+        # always through _compile: it compares the FULL key (device, precision, input size, weights version), so a net the
+        # module compiled for another size / precision by a direct model(x) call is never run on this engine's buffers
+        before = self.model._net[0] if self.model._net is not None else None
+        if self._locked and before is not None:
+            prec = _PREC.get(str(self.model.precision).lower())
+            key = (self.device.index, prec, self.S, self.S, self.model._weights_version())
+            if self.model._net[1] != key or self.model._net[2] < self.max_batch:
+                raise _lib.PopnetError("PoseEngine: the module was recompiled or modified while the engine is locked / captured "
+                                       "(a captured hipGraph still refers to the old pn_net)")
+        return self.model._compile(self.device, self.max_batch, self.S, self.S)
 
     def lock(self, locked=True):
         """Freeze the net's launch descriptors (call after a warm-up forward, before capturing a hipGraph)."""
         net = self.net
         (self.model._ctx or self.ctx).check(self.L.pn_net_lock(net, 1 if locked else 0), "pn_net_lock")
+        self._locked = bool(locked)
 
     # ---- stages (all asynchronous on the current stream) --------------------------------------
     def preprocess(self, depth):
@@ -158,6 +171,7 @@ class YoloEngine:
         self.out = torch.empty((self.max_batch, len(self.anchors) * 50, self.S // 16, self.S // 16), device=d,
                                dtype=torch.float32)
         self.frames = torch.empty((self.max_batch, _lib.YOLO_FRAME_DTYPE.itemsize), device=d, dtype=torch.uint8)
+        self._locked = False
         self.flops_per_frame = self.L.pn_net_flops_per_frame(self.net)
 
     preprocess = PoseEngine.preprocess

@@ -83,9 +83,12 @@ class TrainEngine:
         return _lib.current_stream_ptr(self.device)
 
     def _buf(self, name, shape, zero=False):
-        t = self._bufs.get(name)
-        if t is None or tuple(t.shape) != tuple(shape):
-            t = self._bufs[name] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        # keyed by (name, shape): a step at another batch shape gets its own buffers and never frees the ones a captured
+        # graph of the first shape still points to
+        key = (name, tuple(shape))
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(shape, dtype=torch.float32, device=self.device)
         if zero:
             t.zero_()
         return t
@@ -324,6 +327,8 @@ class TrainEngine:
             self.step(*batch)
         torch.cuda.synchronize(self.device)
         self._static = [t.clone() for t in batch]
+        # the graph will point into the context's scratch: a later, larger eager step must retire that block, not free it
+        self._check(self.L.pn_train_ws_keep(self.ctx.handle, 1), "pn_train_ws_keep")
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))

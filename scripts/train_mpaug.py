@@ -108,6 +108,10 @@ def main(argv=None):
     module.precision = "fp32"
     plateau, best, captured_lr = Plateau(), float("inf"), None
     os.makedirs(args.output_dir, exist_ok=True)
+    if args.batch_size % world:
+        # DataParallel would give the first replicas one sample more; a silent `//` would instead drop batch_size % world
+        # samples of every batch and change the effective batch size
+        raise SystemExit("--batch-size %d is not divisible by the %d replicas" % (args.batch_size, world))
     per_rank = args.batch_size // world               # DataParallel splits the batch over the replicas
     for epoch in range(args.epochs):
         order = list(range(len(train_set)))
@@ -127,6 +131,12 @@ def main(argv=None):
                 print("Epoch: [%d][%d/%d]\tLoss %.4f\t%s\t(%.1f frames/s)" % (epoch, i, n_batches, run, "  ".join("%s %.4f" % (n, v) for n, v in zip(LOSS_NAMES, tl)),
                                                                               (i + 1) * args.batch_size / max(time.time() - t0, 1e-9)))
         val = run
+        if val_set is None and world > 1:
+            # without a validation split the plateau rule runs on the last printed training loss: every rank must take the
+            # SAME lr decision (it is baked into each rank's captured graph), so rank 0's figure is broadcast
+            v = torch.tensor([run], device=dev, dtype=torch.float64)
+            dist.broadcast(v, src=0)
+            val = float(v[0])
         if val_set is not None:
             module.load_state_dict(eng.state_dict())
             module.eval()

@@ -2,7 +2,8 @@
 """Generates the golden vectors under tests/golden/ by running the REFERENCE ITSELF
 (/root/reference, imported read-only in the build container) on seeded inputs.
 
-    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz / *.json
+    python tests/golden/make_golden.py [steps]          # rewrites tests/golden/*.npz / *.json
+    python tests/golden/make_golden.py --check [steps]  # regenerates into a scratch dir and compares (tests/test_golden_recipe.py)
 
 Only data leaves this script: inputs (or the seeds that regenerate them through
 popnet_amd.synth) and the reference's outputs.  No reference source is copied.
@@ -23,6 +24,7 @@ import textwrap
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE          # --check redirects the outputs to a scratch directory and compares them with the committed files
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 TPM = os.path.join(REF, "third_party_methods")
@@ -76,10 +78,13 @@ SHIMS = {
                 return t.sub(m).div(s)
         transforms = types.ModuleType('torchvision.transforms')
         transforms.Compose, transforms.ToTensor, transforms.Normalize = Compose, ToTensor, Normalize
-        transforms.__getattr__ = lambda k: _Dummy
+        def _ga(k):
+            if k.startswith('__'): raise AttributeError(k)      # inspect.getmodule() probes __file__ on every module
+            return _Dummy
+        transforms.__getattr__ = _ga
         sys.modules['torchvision.transforms'] = transforms
         for sub in ('datasets', 'models', 'utils'):
-            mm = types.ModuleType('torchvision.' + sub); mm.__getattr__ = lambda k: _Dummy
+            mm = types.ModuleType('torchvision.' + sub); mm.__getattr__ = _ga
             sys.modules['torchvision.' + sub] = mm; globals()[sub] = mm
     """,
 }
@@ -114,7 +119,7 @@ def golden_state_dicts():
     out = {}
     for name, m in (("rtpose_light3d", rtpose_light3d(15, 14, 2, input_dim=1)), ("yolo_posenet", YoloPoseNet(15, input_dim=1))):
         out[name] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
-    json.dump(out, open(os.path.join(HERE, "state_dict_keys.json"), "w"))
+    json.dump(out, open(os.path.join(OUT, "state_dict_keys.json"), "w"))
     print("F5 state_dict keys:", {k: len(v) for k, v in out.items()})
 
 
@@ -157,7 +162,7 @@ def golden_forward():
                 y = model(torch.from_numpy(x))
                 feat = model.model0(torch.from_numpy(x))
                 out.update(yolo_out=y.numpy(), yolo_feat=feat.numpy()[:, ::8, ::2, ::2])
-    np.savez_compressed(os.path.join(HERE, "forward.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "forward.npz"), **out)
     print("F1 forward:", {k: v.shape for k, v in out.items()})
 
 
@@ -222,7 +227,7 @@ def golden_parse():
         out["%s_insum" % name] = np.array([float(heat.astype(np.float64).sum()), float(paf.astype(np.float64).sum())])
         print("F2 %-20s peaks %3d persons %2d" % (name, len(out["%s_joint_list" % name]), len(out["%s_assoc" % name])))
     out["case_names"] = np.array(sorted(cases))
-    np.savez_compressed(os.path.join(HERE, "parse_paf.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "parse_paf.npz"), **out)
 
 
 # ---- F3: yolo decode -------------------------------------------------------------------------
@@ -258,7 +263,7 @@ def golden_yolo():
             out["s%d_%d_human" % (seed, i)] = np.array(h[i], dtype=np.float32).reshape(-1, 15, 3)
             out["s%d_%d_vis" % (seed, i)] = np.array(v[i], dtype=bool).reshape(-1, 15)
             print("F3 seed %d img %d: %d boxes" % (seed, i, len(b[i])))
-    np.savez_compressed(os.path.join(HERE, "parse_yolo.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "parse_yolo.npz"), **out)
 
 
 # ---- F4: process_paf (compiled reference C++) ------------------------------------------------
@@ -318,7 +323,7 @@ def golden_pafprocess():
         humans = ref.run(pk, heat, paf)
         out["s%d_p%d" % (seed, P)] = humans_to_array(humans)
         print("F4 process_paf seed %d P=%d -> %d humans" % (seed, P, len(humans)))
-    np.savez_compressed(os.path.join(HERE, "pafprocess.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "pafprocess.npz"), **out)
 
 
 # ---- F6: the reference evaluation SCRIPT, end to end, on a fake two-frame dataset ---------------
@@ -376,7 +381,7 @@ def golden_script():
     keep["heat_bias_shift"] = shift.tolist()
     keep["depth_seed"] = 77
     keep["weight_seed"] = 0
-    json.dump(keep, open(os.path.join(HERE, "script_eval_data.json"), "w"))
+    json.dump(keep, open(os.path.join(OUT, "script_eval_data.json"), "w"))
     print("F6 script: persons per frame", [len(f) for f in keep["human_pred_set_2d"]])
 
 
@@ -448,7 +453,7 @@ def golden_script_yolo():
     keep["conf_weight_shift"] = delta
     keep["depth_seed"] = 78
     keep["weight_seed"] = 1
-    json.dump(keep, open(os.path.join(HERE, "script_eval_data_yolo.json"), "w"))
+    json.dump(keep, open(os.path.join(OUT, "script_eval_data_yolo.json"), "w"))
     print("F7 yolo script: persons per frame", [len(f) for f in keep["human_pred_set_2d"]])
 
 
@@ -516,7 +521,7 @@ def golden_metrics():
         a2 = RA.eval_ap_mpii_v2(copy.deepcopy(g2), [], copy.deepcopy(g2), gt_visibility_set=[], head_id=0, neck_id=1, joint_names=names, thresh=0.5)
         d2, k2 = RP.eval_human_dataset_2d_PCKh(copy.deepcopy(g2), copy.deepcopy(g2), num_joints=15, head_id=0, neck_id=1, iou_th=0.5)
     out["perfect"] = {"seed": 104, "ap2d": np.asarray(a2).tolist(), "pck2d": [float(v) for v in k2]}
-    json.dump(out, open(os.path.join(HERE, "metrics.json"), "w"))
+    json.dump(out, open(os.path.join(OUT, "metrics.json"), "w"))
 
 
 # ---- F9: end-to-end metrics: the reference's evaluation script + its own metric code on a 12-frame synthetic split ----
@@ -606,7 +611,7 @@ def golden_script_metrics(net="rtpose"):
            "persons_per_frame": [len(f) for f in p2],
            "pck2d": [float(v) for v in k2], "err2d": [float(v) for v in d2], "pck3d": [float(v) for v in k3], "err3d": [float(v) for v in d3],
            "ap2d": np.asarray(a2).tolist(), "ap3d": np.asarray(a3).tolist()}
-    json.dump(out, open(os.path.join(HERE, "script_metrics.json" if net == "rtpose" else "script_metrics_yolo.json"), "w"))
+    json.dump(out, open(os.path.join(OUT, "script_metrics.json" if net == "rtpose" else "script_metrics_yolo.json"), "w"))
     print("F9 (%s): persons/frame" % net, out["persons_per_frame"], "GT/frame", [len(f) for f in g2])
     print("F9: PCK2D %.3f PCK3D %.3f AP2D %.2f AP3D %.2f" % (np.nanmean(k2), np.nanmean(k3), a2[-1], a3[-1]))
 
@@ -710,7 +715,7 @@ def golden_targets():
                     "it%d_image" % idx: image.numpy(), "it%d_heat" % idx: heat.numpy(), "it%d_paf" % idx: paf.numpy(),
                     "it%d_z" % idx: z.numpy(), "it%d_fg" % idx: fg.numpy()})
     out["n_items"] = np.array(2)
-    np.savez_compressed(os.path.join(HERE, "targets.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "targets.npz"), **out)
     print("F10: targets.npz:", len(out), "arrays; persons per composed item", [out["it%d_kp3d" % i].shape[0] for i in range(2)])
 
 
@@ -777,18 +782,80 @@ def golden_train():
             if name.endswith("running_mean") or name.endswith("running_var"):
                 out["s%d_stat/%s" % (step, name)] = b.detach().numpy().copy()
     out["saved_sizes"] = np.array([list(s.shape) for s in saved])
-    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
     print("train_step.npz: loss", out["s0_loss"], "->", out["s1_loss"])
+
+
+def _same(a, b):
+    """Exact comparison of two golden payloads (NaN == NaN); returns a list of differing paths."""
+    bad = []
+
+    def walk(x, y, path):
+        if isinstance(x, dict) and isinstance(y, dict):
+            for k in sorted(set(x) | set(y)):
+                if k not in x or k not in y:
+                    bad.append(path + "/" + str(k) + " (missing)")
+                else:
+                    walk(x[k], y[k], path + "/" + str(k))
+        elif isinstance(x, (list, tuple)) and isinstance(y, (list, tuple)):
+            if len(x) != len(y):
+                bad.append(path + " (length)")
+            else:
+                for i, (u, v) in enumerate(zip(x, y)):
+                    walk(u, v, "%s[%d]" % (path, i))
+        elif isinstance(x, float) and isinstance(y, float):
+            if not (x == y or (x != x and y != y)):
+                bad.append(path)
+        elif x != y:
+            bad.append(path)
+    walk(a, b, "")
+    return bad
+
+
+def check_outputs(scratch):
+    """Compares every file the selected steps wrote into `scratch` with the committed one of the same name."""
+    failures = []
+    for name in sorted(os.listdir(scratch)):
+        new, old = os.path.join(scratch, name), os.path.join(HERE, name)
+        if not os.path.exists(old):
+            failures.append("%s: not committed" % name)
+        elif name.endswith(".npz"):
+            a, b = np.load(new, allow_pickle=False), np.load(old, allow_pickle=False)
+            if sorted(a.files) != sorted(b.files):
+                failures.append("%s: array names differ" % name)
+                continue
+            for k in a.files:
+                x, y = a[k], b[k]
+                if x.shape != y.shape or x.dtype != y.dtype or not np.array_equal(x, y, equal_nan=x.dtype.kind in "fc"):
+                    failures.append("%s[%s]" % (name, k))
+        else:
+            bad = _same(json.load(open(new)), json.load(open(old)))
+            failures += ["%s%s" % (name, b) for b in bad[:5]]
+        print("check %-28s %s" % (name, "differs" if failures and failures[-1].startswith(name) else "identical"))
+    return failures
 
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate golden vectors"
+    import torch.optim                 # noqa: F401  -- before the torchvision shim is importable: these pull in
+    import torch.distributed.tensor    # noqa: F401     inspect.getmodule(), which walks every module in sys.modules
     install_shims()
     import popnet_amd  # noqa: F401
-    which = sys.argv[1:] or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo", "targets", "train"]
+    args = sys.argv[1:]
+    check = "--check" in args
+    args = [a for a in args if a != "--check"]
+    if check:
+        OUT = tempfile.mkdtemp(prefix="popnet_golden_check_")
+    which = args or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo", "targets", "train"]
     fns = {"keys": golden_state_dicts, "forward": golden_forward, "parse": golden_parse, "yolo": golden_yolo,
            "pafprocess": golden_pafprocess, "script": golden_script,
            "script_yolo": golden_script_yolo, "metrics": golden_metrics, "script_metrics": golden_script_metrics,
            "script_metrics_yolo": lambda: golden_script_metrics("yolo"), "targets": golden_targets, "train": golden_train}
     for w in which:
         fns[w]()
+    if check:
+        fails = check_outputs(OUT)
+        if fails:
+            print("GOLDEN CHECK FAILED:\n  " + "\n  ".join(fails))
+            sys.exit(1)
+        print("golden check ok: %d files regenerate identically" % len(os.listdir(OUT)))

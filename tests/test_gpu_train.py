@@ -462,6 +462,14 @@ def test_captured_training_step_equals_eager(gpu, golden):
     # another batch shape falls back to the eager path
     other = [torch.from_numpy(x).to(gpu) for x in train_case_inputs(seed=9, B=1, H=64, W=96)]
     assert torch.equal(eager.step(*other), graph.step(*other))
+    # ... and a LARGER one (new activation buffers, the C-side scratch grows) must not free what the graph points to
+    # (ADVICE r02): the replay at the captured shape right after still equals the eager engine bit for bit
+    big = [torch.from_numpy(x).to(gpu) for x in train_case_inputs(seed=10, B=3, H=96, W=128)]
+    assert torch.equal(eager.step(*big), graph.step(*big))
+    for b in batches[:2]:
+        assert torch.equal(eager.step(*b).clone(), graph.step(*b).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(eager.flat_p, graph.flat_p) and torch.equal(eager.flat_m, graph.flat_m)
 
 
 def test_synthetic_train_eval_script_runs(gpu, capsys, monkeypatch):
