@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = int(os.environ.get("POPNET_BENCH_BATCH", "32"))     # 32 = BASELINE configs[1]; the override is for experiments only
+_PINNED = {}
 PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}      # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -250,54 +251,51 @@ def launcher_dry_run(args):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
-    ap.add_argument("--net", default="rtpose", choices=["rtpose", "yolo"],
-                    help="rtpose = rtpose_light3d + PAF parsing (the headline workload); yolo = YoloPoseNet + box decode (SURVEY 8a rows 7, 12)")
-    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive passes (inputs handed over from pinned host memory)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the fidelity / multi-person legs (profiling runs)")
-    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight per GPU (engines on separate HIP streams)")
-    ap.add_argument("--pool", type=int, default=6, help="distinct input batches per slot (pipeline x pool x 19.7 MB should exceed the 256 MB Infinity Cache)")
-    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region per input mode; the median is reported")
-    ap.add_argument("--launcher-dry-run", action="store_true", help="CPU check of the --gpus N self-launch (gloo, no GPU work)")
-    ap.add_argument("--workload", default="infer", choices=["infer", "train"], help="infer = the headline path (BASELINE configs[1]); train = the training step (configs[4])")
-    args = ap.parse_args()
+def dist_check(dev, world, rank, dist):
+    """RCCL on the hardware: with the process group initialised (backend "nccl" = RCCL; also at
+    world_size 1 under --force-dist) run the two real exchanges of the repo on device tensors and compare with what
+    they must return: pipeline.gather_records (the single all-gather of pose records) and
+    TrainEngine.reduce_flat_gradient (the all-reduce of the 22 MB flat gradient)."""
+    from popnet_amd import _lib
+    from popnet_amd.pipeline import gather_records
+    from popnet_amd.train import TrainEngine
+    item = _lib.POSE_WIRE_DTYPE.itemsize
+    n_frames = 96 * world
+    g = torch.Generator(device="cpu").manual_seed(11)
+    allrec = torch.randint(0, 256, (n_frames, item), dtype=torch.uint8, generator=g)
+    mine = allrec[rank::world].to(dev)
+    t0 = time.perf_counter()
+    got = gather_records(mine, n_frames, rank, world)
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t0
+    gather_ok = bool(torch.equal(got.cpu(), allrec))
+    flat = torch.randn(5525816, generator=g).to(dev)               # the trainer's flat gradient buffer: 22 MB
+    ref = flat.clone()
+    TrainEngine.reduce_flat_gradient(flat, world, None, force=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        TrainEngine.reduce_flat_gradient(flat, world, None, force=True)
+    torch.cuda.synchronize()
+    t_ar = (time.perf_counter() - t1) / 5
+    # world replicas of the same buffer summed 6 times: flat == ref * world ** 6 exactly in fp32 for world = 1, 2, 4, 8
+    allreduce_ok = bool(torch.equal(flat, ref * float(world) ** 6))
+    maps = open("/proc/self/maps").read()
+    libs = sorted({ln.split("/")[-1] for ln in maps.splitlines() if "librccl" in ln or "libnccl" in ln})
+    return {"backend": dist.get_backend(), "world_size": world, "gather_records_ok": gather_ok, "flat_gradient_allreduce_ok": allreduce_ok,
+            "gather_ms": round(t_gather * 1e3, 3), "allreduce_22MB_ms": round(t_ar * 1e3, 3), "collective_library_loaded": libs,
+            "what": "pipeline.gather_records on %d device-resident wire records and TrainEngine.reduce_flat_gradient on the 22 MB flat buffer over the initialised process group" % n_frames}
 
-    from popnet_amd import launch                                   # touches no GPU
-    if args.gpus > 1 and not launch.under_torchrun():
-        # started from a bare shell: become the parent of N fresh ranks (nothing below this line has run, no HIP call yet)
-        sys.exit(launch.relaunch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
-    if args.launcher_dry_run:
-        return launcher_dry_run(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    import popnet_amd  # noqa: F401
-    if args.workload == "train":
-        train_workload(args, dev, world, rank, dist)
-        if world > 1:
-            dist.destroy_process_group()
-        return
+def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_active):
+    """The timed regions of one (network, precision): `--reps` repetitions of the K-step region with the inputs resident in HBM
+    (-> value) and, with want_h2d, handed over from pinned host memory (-> h2d_inclusive), then the eager roofline pass with HIP
+    events around every conv launch.  Returns {"out": the JSON fields (rank 0; None elsewhere), "engine", "depth_host", "se"}."""
     from popnet_amd import _lib, synth
     from popnet_amd.pipeline import PoseEngine, StreamingEngine, YoloEngine
-    Engine = PoseEngine if args.net == "rtpose" else YoloEngine
-    REC = _lib.POSE_FRAME_DTYPE if args.net == "rtpose" else _lib.YOLO_FRAME_DTYPE
-    WIRE = _lib.POSE_WIRE_DTYPE if args.net == "rtpose" else REC
+    Engine = PoseEngine if net == "rtpose" else YoloEngine
+    REC = _lib.POSE_FRAME_DTYPE if net == "rtpose" else _lib.YOLO_FRAME_DTYPE
+    WIRE = _lib.POSE_WIRE_DTYPE if net == "rtpose" else REC
 
     # popnet_amd.pipeline.StreamingEngine: PIPE batches in flight (per slot: engine = activations + private parse scratch,
     # POOL static input buffers, record buffers, a HIP stream, ONE hipGraph of the whole step per input buffer).  Batch k
@@ -305,12 +303,15 @@ def main():
     # overlaps with the convolutions of the next.  Every batch still runs the whole path; only its latency is hidden.
     PIPE, POOL = max(1, args.pipeline), max(1, args.pool)
     NIN = PIPE * POOL
-    se = StreamingEngine(Engine, depth=PIPE, pool=POOL, wire=True, graph=not args.no_graph, precision=args.precision, device=dev, max_batch=BATCH)
+    se = StreamingEngine(Engine, depth=PIPE, pool=POOL, wire=True, graph=not args.no_graph, precision=precision, device=dev, max_batch=BATCH)
     engines, streams = se.engines, se.streams
     engine = engines[0]
     pinned = []                                                  # NIN distinct batches, pinned on the host ...
     for i in range(NIN):
-        h = torch.from_numpy(synth.synth_depth(BATCH, 640, 480, seed=1234 + 1000 * rank + i)).pin_memory()
+        seed = 1234 + 1000 * rank + i
+        if seed not in _PINNED:                                  # shared by the legs of one run (same frames in every mode)
+            _PINNED[seed] = torch.from_numpy(synth.synth_depth(BATCH, 640, 480, seed=seed)).pin_memory()
+        h = _PINNED[seed]
         pinned.append(h)
         se.input(i // POOL, i % POOL).copy_(h)                   # ... and resident in HBM (slot i // POOL, buffer i % POOL)
     depth_host = pinned[0].numpy()
@@ -318,7 +319,7 @@ def main():
     K, W = args.steps, args.warmup
     witem = WIRE.itemsize
     keep = torch.empty((K, BATCH, witem), device=dev, dtype=torch.uint8)       # every step's host-bound records (checks, gather)
-    gathered = torch.empty((world * K * BATCH, witem), device=dev, dtype=torch.uint8) if world > 1 else None
+    gathered = torch.empty((world * K * BATCH, witem), device=dev, dtype=torch.uint8) if dist_active else None
 
     batch_of = [0] * K                                           # which of the NIN batches step k of the LAST region ran
 
@@ -339,7 +340,7 @@ def main():
 
     def region(h2d):
         """K steps, barrier + device sync on both sides, max over ranks.  Returns seconds."""
-        if world > 1:
+        if dist_active:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -347,13 +348,13 @@ def main():
             step(k, h2d)
         host_enqueue_s[h2d] = time.perf_counter() - t0           # how long the host needed to enqueue the K steps
         se.join()
-        if world > 1:
+        if dist_active:
             dist.all_gather_into_tensor(gathered, keep.view(K * BATCH, witem))
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_active:
             dist.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist_active:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -363,14 +364,14 @@ def main():
     for i in range(max(W, 2 * PIPE)):
         step(i % K, False)
     se.join()
-    if world > 1:
+    if dist_active:
         dist.all_gather_into_tensor(gathered, keep.view(K * BATCH, witem))
     torch.cuda.synchronize()
 
     REPS = max(1, args.reps)
     runs = {"resident": [region(False) for _ in range(REPS)]}
     keep_res, batch_res = keep.cpu(), list(batch_of)
-    if not args.no_h2d:
+    if want_h2d:
         region(True)                                             # one untimed pass: first touch of the pinned pool
         runs["h2d"] = [region(True) for _ in range(REPS)]
         keep_h2d, batch_h2d = keep.cpu(), list(batch_of)
@@ -422,6 +423,7 @@ def main():
                         "flops_per_launch": round(kfl.value / max(kn.value, 1), 1)})
     frames_full = torch.stack([se.records(s) for s in range(PIPE)]).cpu()
 
+    out = None
     if rank == 0:
         first = {}                                               # the same input batch must give the same records, whatever step / slot / input mode ran it
 
@@ -439,9 +441,9 @@ def main():
         recs = frames_full.numpy().view(REC).reshape(PIPE, BATCH)
         total_frames = world * K * BATCH
         achieved = conv_flops.value / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
-        peak = PEAK_TFLOPS[args.precision]
+        peak = PEAK_TFLOPS[precision]
         # network outputs read + records written per frame
-        post_bytes = BATCH * ((185024 if args.net == "rtpose" else 100 * 14 * 14 * 4) + witem)
+        post_bytes = BATCH * ((185024 if net == "rtpose" else 100 * 14 * 14 * 4) + witem)
         dom = kernels[0] if kernels else {"kernel": "none", "us_per_step": 0.0, "avg_launch_us": 0.0, "tflops": 0.0, "flops_per_launch": 0.0, "launches_per_step": 0}
         traffic = None                                          # HBM bytes per launch of the dominant kernel (separate rocprofv3 --pmc passes)
         pmc = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
@@ -460,13 +462,13 @@ def main():
             "value_stat": {"what": "median of %d repetitions of the %d-step timed region" % (REPS, K), "min": rate(max(runs["resident"])), "max": rate(min(runs["resident"])),
                            "runs": [rate(v) for v in runs["resident"]]},
             "launch_mode": ("eager" if args.no_graph else "hipGraph replay (one graph per step)") + ", %d batches in flight on separate HIP streams" % PIPE, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision,
+            "vs_baseline": None, "dtype": precision,
             "data": "synthetic, %d distinct batches (%.0f MB) resident in HBM, a different batch every step" % (NIN, NIN * BATCH * 640 * 480 * 2 / 1e6),
             "config": {"workload": "BASELINE configs[1]: batch=32 synthetic 480x640 f16 depth frames per GPU per step, "
-                                   "resize->224^2, " + ("rtpose_light3d forward + PAF pose parsing" if args.net == "rtpose" else
+                                   "resize->224^2, " + ("rtpose_light3d forward + PAF pose parsing" if net == "rtpose" else
                                                         "YoloPoseNet forward + box decode / NMS / skeleton read-out (secondary network of the path)") + ", records D2H",
                        "frames_per_step_per_gpu": BATCH, "input": "480x640 f16", "network_input": "224x224",
-                       "weights": "seeded random, " + ("heat head calibrated (pipeline.calibrate_heads)" if args.net == "rtpose" else "confidence filters calibrated (pipeline.calibrate_yolo_conf)"),
+                       "weights": "seeded random, " + ("heat head calibrated (pipeline.calibrate_heads)" if net == "rtpose" else "confidence filters calibrated (pipeline.calibrate_yolo_conf)"),
                        "records": "pn_pose_wire (%d B per frame) to pinned host memory every step" % witem if se.wire else "pn_yolo_frame to pinned host memory every step",
                        "parallelism": "frames sharded x%d, one all-gather of records" % world},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"] + " (dominant convolution instantiation: %.0f of %.0f conv us/step)" % (dom["us_per_step"], conv_ms.value * 1e3 / K),
@@ -477,14 +479,14 @@ def main():
                                         "ms_per_step": round(conv_ms.value / K, 4), "tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
                                         "stem_pool_ms_per_step": round(other_ms.value / K, 4), "by_kernel": kernels},
                          "measured": "HIP events around every conv launch on the launch stream, the same %d steps re-run eagerly on one engine right after the timed regions (%.4f ms/step with events)" % (K, elapsed_profiled / K * 1e3)},
-            "postproc": {"bound": "hbm", "kernels": "pose parsing (NMS + refine, limb scoring + matching, assembly + read-out)" if args.net == "rtpose" else "box decode + NMS + skeleton read-out",
+            "postproc": {"bound": "hbm", "kernels": "pose parsing (NMS + refine, limb scoring + matching, assembly + read-out)" if net == "rtpose" else "box decode + NMS + skeleton read-out",
                          "algorithmic_bytes_per_step": post_bytes, "us_per_step": round(post_ms * 1e3, 2),
                          "achieved": round(post_bytes / (post_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(post_bytes / (post_ms * 1e-3) / 8e12, 5), "pack_us_per_step": round(pack_ms * 1e3, 2), "record_d2h_us_per_step": round(d2h_ms * 1e3, 2),
                          "note": "latency-bound: 32 small frames per step; hidden behind the next batch by the StreamingEngine"},
             "host_enqueue_ms_per_step": {("h2d" if m else "resident"): round(v / K * 1e3, 4) for m, v in host_enqueue_s.items()},
-            "frame_stats": {"mean_peaks": round(float(recs['n_peaks' if args.net == "rtpose" else 'n_candidates'].mean()), 2),
-                            "mean_persons": round(float(wire['n_persons' if args.net == "rtpose" else 'n_det'].mean()), 3),
+            "frame_stats": {"mean_peaks": round(float(recs['n_peaks' if net == "rtpose" else 'n_candidates'].mean()), 2),
+                            "mean_persons": round(float(wire['n_persons' if net == "rtpose" else 'n_det'].mean()), 3),
                             "overflow_frames": int((wire['status'] != 0).sum()),
                             "same_batch_same_records_across_steps_slots_and_input_modes": same},
         }
@@ -492,14 +494,109 @@ def main():
             out["h2d_inclusive"] = {"value": rate(med["h2d"]), "unit": "frames/s", "ms_per_step": round(med["h2d"] / K * 1e3, 4),
                                     "min": rate(max(runs["h2d"])), "max": rate(min(runs["h2d"])), "runs": [rate(v) for v in runs["h2d"]],
                                     "what": "same region, every batch copied from pinned host memory inside the region (StreamingEngine.submit_host: %.1f MB per step over PCIe on the copy stream, into the slot's next input buffer while its current step runs): first H2D enqueue to last record on host, median of %d" % (BATCH * 640 * 480 * 2 / 1e6, REPS)}
-        if world == 1 and args.net == "rtpose" and not args.no_extras:
+    se_engine, host0 = engine, depth_host
+    return {"out": out, "engine": se_engine, "depth_host": host0, "se": se}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
+    ap.add_argument("--net", default="rtpose", choices=["rtpose", "yolo"],
+                    help="rtpose = rtpose_light3d + PAF parsing (the headline workload); yolo = YoloPoseNet + box decode (SURVEY 8a rows 7, 12)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive passes (inputs handed over from pinned host memory)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fidelity / multi-person legs (profiling runs)")
+    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight per GPU (engines on separate HIP streams)")
+    ap.add_argument("--pool", type=int, default=6, help="distinct input batches per slot (pipeline x pool x 19.7 MB should exceed the 256 MB Infinity Cache)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region per input mode; the median is reported")
+    ap.add_argument("--launcher-dry-run", action="store_true", help="CPU check of the --gpus N self-launch (gloo, no GPU work)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run every exchange even at world_size 1 (in a fresh child rank started before any GPU call)")
+    ap.add_argument("--workload", default="infer", choices=["infer", "train"], help="infer = the headline path (BASELINE configs[1]); train = the training step (configs[4])")
+    args = ap.parse_args()
+
+    from popnet_amd import launch                                   # touches no GPU
+    if (args.gpus > 1 or args.force_dist) and not launch.under_torchrun():
+        # started from a bare shell: become the parent of N fresh ranks (nothing below this line has run, no HIP call yet)
+        sys.exit(launch.relaunch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.launcher_dry_run:
+        return launcher_dry_run(args)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    dist_active = world > 1 or args.force_dist
+    if dist_active:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import popnet_amd  # noqa: F401
+    if args.workload == "train":
+        train_workload(args, dev, world, rank, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    legs = pipelined_leg(args, dev, world, rank, dist, args.net, args.precision, want_h2d=not args.no_h2d, dist_active=dist_active)
+    if rank == 0:
+        out = legs["out"]
+        engine = legs["engine"]
+        default_line = world == 1 and args.net == "rtpose" and not args.no_extras
+        if dist_active:
+            out["dist"] = dist_check(dev, world, rank, dist)
+        if default_line:
             out["mpaug_parse"] = mpaug_parse_leg(engine)
             out["precision_modes"] = precision_modes_leg(dev)
-            out["train_step"] = train_step_leg(dev, cpu=not args.no_cpu_baseline)
+            # the headline dtype's own fidelity next to `value`: no reader can take the bf16 figure as a within-tolerance one
+            fid = out["precision_modes"].get(args.precision, {}).get("vs_fp32_threshold_calibrated_weights")
+            sep = out["precision_modes"].get(args.precision, {}).get("vs_fp32_separated_weights")
+            if fid is not None:
+                out["fidelity"] = {"dtype": args.precision, "vs": "the fp32 engine (the mode that equals the reference's CPU path), 96 frames",
+                                   "same_assignment": "%d/%d" % (fid["same_assignment"], fid["frames"]), "d3_m_max": fid["d3_m_max"],
+                                   "separated_weights": {"same_assignment": "%d/%d" % (sep["same_assignment"], sep["frames"]), "d3_m_max": sep["d3_m_max"]},
+                                   "meets_north_star_tolerance": bool(fid["d3_m_max"] < 1e-3 and fid["same_assignment"] >= fid["frames"] - 2),
+                                   "note": "north_star: joints within 1e-3 m, identical person assignment. The mode that meets it at matrix-core rate is `parity_mode` below."}
+        cpu_eng_depth = (engine, legs["depth_host"])
         if world == 1 and not args.no_cpu_baseline and args.net == "rtpose":
-            out["cpu_baseline"] = cpu_baseline(engine, depth_host)
+            out["cpu_baseline"] = cpu_baseline(*cpu_eng_depth)
+    legs = None
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.net == "rtpose" and not args.no_extras and args.precision == "bf16":
+        # the tolerance-meeting fast mode through the SAME region code, then the secondary network
+        pm = pipelined_leg(args, dev, world, rank, dist, "rtpose", "bf16x3", want_h2d=not args.no_h2d, dist_active=False)["out"]
+        x3 = out["precision_modes"]["bf16x3"]
+        rf = pm["roofline"]
+        out["parity_mode"] = {
+            "dtype": "bf16x3", "value": pm["value"], "unit": "frames/s", "ms_per_step": pm["ms_per_step"], "value_stat": pm["value_stat"],
+            "h2d_inclusive": pm.get("h2d_inclusive"),
+            "roofline": {"bound": "mfma", "kernel": rf["kernel"], "achieved": round(3 * rf["achieved"], 2), "peak": rf["peak"], "unit": "TFLOP/s",
+                         "frac": round(3 * rf["achieved"] / rf["peak"], 4), "algorithmic_tflops": rf["achieved"], "avg_launch_us": rf["avg_launch_us"],
+                         "what": "physical bf16 MFMA FLOPs = 3 x algorithmic (x_hi W_hi + x_lo W_hi + x_hi W_lo)",
+                         "conv_stack_algorithmic_tflops": rf["conv_stack"]["achieved"], "conv_stack_physical_frac": round(3 * rf["conv_stack"]["frac"], 4)},
+            "fidelity": {"threshold_calibrated_weights": x3["vs_fp32_threshold_calibrated_weights"], "separated_weights": x3["vs_fp32_separated_weights"]},
+            "what": "the same pipelined timed region (hipGraph replay, %d batches in flight, median of %d) with precision='bf16x3': every tensor as three bf16 planes, fp32-class results" % (args.pipeline, args.reps)}
+        gc.collect()
+        torch.cuda.empty_cache()
+        yl = pipelined_leg(args, dev, world, rank, dist, "yolo", "bf16", want_h2d=False, dist_active=False)["out"]
+        out["yolo"] = {"value": yl["value"], "unit": "frames/s", "ms_per_step": yl["ms_per_step"], "value_stat": yl["value_stat"], "dtype": "bf16",
+                       "roofline": {k: yl["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step")},
+                       "conv_stack": {k: yl["roofline"]["conv_stack"][k] for k in ("achieved", "frac", "launches_per_step", "ms_per_step", "by_kernel")},
+                       "frame_stats": yl["frame_stats"],
+                       "what": "YoloPoseNet forward + box decode / NMS / skeleton read-out (SURVEY 8a rows 7, 12) through the same pipelined region"}
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["train_step"] = train_step_leg(dev, cpu=not args.no_cpu_baseline)
+    if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

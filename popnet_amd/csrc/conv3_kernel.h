@@ -43,6 +43,12 @@ __device__ __forceinline__ void pn_glds16(gcptr src, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 
+// 16-byte write-through store (sc1): the line is written to memory at once and dropped from the XCD's L2 (no dirty line is
+// left for the end-of-kernel write-back).  Inline asm: hipcc keeps no vmcnt bookkeeping for it -- stores need none.
+__device__ __forceinline__ void pn_store16_wt(PN_GLOBAL void *p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+
 // LDS-DMA, scalar base + 32-bit lane offset: no 64-bit address registers, the per-step pointer bump is scalar.
 template <int IMM>
 __device__ __forceinline__ void pn_glds16_s(const void *sbase, unsigned voff, unsigned lds_dst) {

@@ -28,15 +28,24 @@
 #include "conv3_kernel.h"
 
 #define PN4_ASLOT 8192                  // one k-step of weight fragments: 8 cout tiles x 1 KB
-#define PN4_ARING (3 * PN4_ASLOT)
-#define PN4_BQUART (6 * 32 * 32)        // one 16-channel quarter plane of a strip image: 6 halo rows x 32 px x 32 B
+#ifndef PN4_RING
+#define PN4_RING 3                      // weight ring slots (3: slot = immediate; 4: runtime slot, no LDS-read drain at the barrier)
+#endif
+#ifndef PN4_PITCH
+#define PN4_PITCH 32                    // halo pixels per LDS row (36: a 16-pixel tile that wraps a 28-pixel row stays conflict-free)
+#endif
+#ifndef PN4_LGKM
+#define PN4_LGKM 0                      // LDS reads left in flight at the k-step barrier (3 = the three B reads issued last)
+#endif
+#define PN4_ARING (PN4_RING * PN4_ASLOT)
+#define PN4_BQUART (5 * PN4_PITCH * 32 + 1024)   // one 16-channel quarter plane of a strip image: 6 halo rows x PITCH px x 32 B (the last row: the 1 KiB a DMA writes)
 #define PN4_BSTRIP (2 * PN4_BQUART)     // one 32-channel half image of one strip
 #define PN4_BBUF (2 * PN4_BSTRIP)       // both strips
 #define PN4_LDS (PN4_ARING + 2 * PN4_BBUF)
 
 __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__restrict__ probs) {
     typedef __bf16 T;
-    constexpr int KS = 3, KK = 9, PT = 7, CT = 4, PITCH = 32;
+    constexpr int KS = 3, KK = 9, PT = 7, CT = 4, PITCH = PN4_PITCH, RING = PN4_RING;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const ConvProblem &P = probs[blockIdx.y];
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
     }
     const int nhalves = nchunks * 2;
     auto dma_b = [&](int j, int buf, int hh) {       // piece j of half hh -> image `buf` of this strip
-        const unsigned dst = (unsigned)(PN4_ARING + buf * PN4_BBUF + j * 1024) +
+        const unsigned dst = (unsigned)(PN4_ARING + buf * PN4_BBUF + j * (PITCH * 32)) +
                              (unsigned)__builtin_amdgcn_readfirstlane(wp * PN4_BSTRIP + wc * PN4_BQUART);
         pn_glds16_s<0>(img + (size_t)(hh < nhalves ? hh : 0) * 64, boff[j], dst);   // past the last half: a harmless refetch into the idle image
     };
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
         baddr[pt] = PN4_ARING + wp * PN4_BSTRIP + (q >> 1) * PN4_BQUART + (q & 1) * 16 + (ry * PITCH + rx) * 32;
     }
     const int aaddr = wc * 4096 + lane * 16;
+    static_assert(RING == 3 || RING == 4, "weight ring: 3 slots (immediate slot offsets) or 4 (runtime slot)");
     f32x4 acc[CT][PT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -164,12 +174,15 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
             for (int ph = 0; ph < 2 * KK; ++ph) {            // k-step s = chunk * 18 + ph
                 const int tap = ph % KK, half = ph / KK;
                 const int hh = chunk * 2 + half;
+                // RING == 4: k-step s lives in slot s & 3 (wave-uniform, computed on the scalar unit + one v_add per step)
+                const int sstep = chunk * (2 * KK) + ph;
+                const int anext = RING == 3 ? aaddr + ((ph + 1) % 3) * PN4_ASLOT : aaddr + (int)__builtin_amdgcn_readfirstlane(((sstep + 1) & 3) * PN4_ASLOT);
                 // (1) staging for later steps: one halo piece of the NEXT half (taps 0..5), the weight fragments of step s + 3
 #ifndef PN4_FAKE_NODMA_B                        // -DPN4_FAKE_*: timing-only ablations (wrong results), scripts/conv4lab.hip
                 if (tap < 6) dma_b(tap, (half + 1) & 1, hh + 1);
 #endif
 #ifndef PN4_FAKE_NODMA_A
-                dma_a(ph % 3);
+                dma_a(RING == 3 ? ph % 3 : (int)__builtin_amdgcn_readfirstlane((sstep + 3) & 3));
 #endif
                 // (2) this step's 28 MFMAs; fragment reads for the next step / the next items between them
                 if (MATH) {
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                         const int j = ph * PT + pt, jr = j + BQ - 1;
 #ifndef PN4_FAKE_NOLDS
                         if (pt < CT)
-                            aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % 3) * PN4_ASLOT + pt * 1024);
+                            aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + anext + pt * 1024);
                         bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + baddr[jr % PT] + PN4_BOFF(jr % (2 * KK * PT)));
 #endif
 #pragma unroll
@@ -198,8 +211,20 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
 #elif defined(PN4_FAKE_NODMA_A) || defined(PN4_FAKE_NODMA_B)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
+#if PN4_RING == 4
+                // 4 slots: the slot refilled in step s + 1 was last read in step s - 1 and the image refilled during a half was
+                // last read before the previous half's final MFMAs -- no LDS read has to drain here
+                if (tap < 6) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+#elif PN4_LGKM == 3
+                // the three LDS reads issued last in a step are B fragments of later items (checked in the ISA): only the A reads
+                // (the slot refilled right after this barrier) have to be back
+                if (tap < 6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(3)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(3)\n\ts_barrier" ::: "memory");
+#else
                 if (tap < 6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 #endif
             }
             PN_STAMP_AT(3 + 2 * (chunk & 3));
@@ -239,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
             for (int pt = 0; pt < PT; ++pt) {
                 const int slot = pt * 16 + c;
                 const unsigned t = (unsigned)(baddr[pt] - PN4_ARING - wp * PN4_BSTRIP - (q >> 1) * PN4_BQUART) >> 5;     // ry * 32 + rx
-                const unsigned opix = pix0 + (t >> 5) * (unsigned)Wo + (t & 31u);
+                const unsigned opix = PITCH == 32 ? pix0 + (t >> 5) * (unsigned)Wo + (t & 31u) : pix0 + (t / (unsigned)PITCH) * (unsigned)Wo + (t % (unsigned)PITCH);
                 float v[LC];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
@@ -271,8 +296,15 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                     }
                     if (slot < npix) {
                         PN_GLOBAL u32x4 *op = reinterpret_cast<PN_GLOBAL u32x4 *>(ob + (opix * (unsigned)out_cs + (unsigned)(pl * split)));
+#ifdef PN4_WT_STORE
+                        // write-through (sc1): the tile leaves the XCD's L2 now, while other blocks still compute, instead of in
+                        // the end-of-kernel write-back of ~23 MB of dirty lines that the next launch has to wait for
+                        pn_store16_wt(op, reinterpret_cast<u32x4 *>(ov)[0]);
+                        pn_store16_wt(op + 1, reinterpret_cast<u32x4 *>(ov)[1]);
+#else
                         op[0] = reinterpret_cast<u32x4 *>(ov)[0];
                         op[1] = reinterpret_cast<u32x4 *>(ov)[1];
+#endif
                     }
                 }
             }

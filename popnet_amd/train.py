@@ -278,11 +278,12 @@ class TrainEngine:
         return self.loss_terms
 
     @staticmethod
-    def reduce_flat_gradient(flat_g, world, group=None):
+    def reduce_flat_gradient(flat_g, world, group=None, force=False):
         """The data-parallel exchange of a step: ONE all-reduce (sum) of the flat gradient buffer over the replicas; the 1 / world
         of DataParallel's mean is applied inside pn_sgd_nesterov (grad_scale).  Returns that scale.  (RCCL on the GPUs; the
-        world_size-2 gloo test drives exactly this function on CPU tensors.)"""
-        if world > 1:
+        world_size-2 gloo test drives exactly this function on CPU tensors.)  force: run the collective at world 1 as well
+        (bench.py --force-dist: puts RCCL on the hardware of a one-GPU box)."""
+        if world > 1 or force:
             import torch.distributed as dist
             dist.all_reduce(flat_g, group=group)
         return 1.0 / world
