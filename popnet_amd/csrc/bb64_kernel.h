@@ -16,12 +16,15 @@
 //   * the input image is double-buffered: the next tile's image is fetched during this tile's conv1, the stores of
 //     this tile drain under the next tile's conv1 -- no lockstep memory phases;
 //   * 8 waves with FIXED ROLES: waves 0-3 compute (each 64 couts x 5 / 4 pixel tiles: 20 / 16 MFMAs per k-step, B
-//     fragments from the images, A fragments from a 3-slot LDS ring), waves 4-7 only issue LDS-DMA (weights: one 4 KB
-//     k-step per phase, W1 | W2 as one periodic 36-step stream; input image pieces) and count their own vmcnt -- a
-//     compute wave's instruction stream is MFMA + ds_read only (conv4_kernel's ablations: DMA issue and its waits cost a
-//     lone wave 80 of 717 cycles per k-step);
-//   * one barrier per k-step (a bare s_barrier for the compute waves: their fragment reads stay in flight across it), 152 KB
-//     of LDS, one workgroup per CU.
+//     fragments from the images, A fragments from a 6-slot LDS ring), waves 4-7 only issue LDS-DMA and count their own
+//     vmcnt -- a compute wave's instruction stream is MFMA + ds_read only (conv4_kernel's ablations: DMA issue and its
+//     waits cost a lone wave 80 of 717 cycles per k-step).  Round 3: the loaders are split by STREAM -- waves 4, 5 fetch
+//     weights (W1 | W2 as one periodic 36-step stream, L2-resident: one 4 KB k-step each per phase, landed one phase later),
+//     waves 6, 7 the next tile's input image (HBM / Infinity Cache latency) and wait for it only at the end of the tile.
+//     vmcnt retires in issue order, so with both streams on one wave (round 2) every phase of conv1 waited for an image
+//     piece issued one phase earlier: 530 cycles per 320-cycle phase against 355 per 256 in conv2 (scripts/bblab.hip);
+//   * one barrier per TWO k-steps (a bare s_barrier for the compute waves: their fragment reads stay in flight across it):
+//     20 barriers per tile instead of 38; 160 KB of LDS, one workgroup per CU.
 // Weight pack (net.hip): [36 k-steps = (conv, half, tap)][4 cout tiles][64 lanes][8 bf16], rows permuted with
 // pn_conv_row_channel(tile, row, 4) so that a lane's 16 accumulators are 16 consecutive channels.
 #pragma once
@@ -40,8 +43,8 @@
 #define BB_ASLOT 4096
 #define BB_OFF_MID (2 * BB_IN)
 #define BB_OFF_A (BB_OFF_MID + BB_MID)
-#define BB_NSLOT 4                              // weight ring: k-step ph + 3 lands in the slot whose last reader finished a full phase ago
-#define BB_LDS (BB_OFF_A + BB_NSLOT * BB_ASLOT) // 155648 B
+#define BB_NSLOT 6                              // weight ring: a phase = 2 k-steps; phase p + 2 lands in the slots of phase p - 1
+#define BB_LDS (BB_OFF_A + BB_NSLOT * BB_ASLOT) // 163840 B = all of a CU's LDS
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -73,14 +76,43 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         // ================= loader waves: LDS-DMA only =================
         const int lw = wave - 4;
         const unsigned lane16 = (unsigned)lane * 16u;
-        const char *wsrc0 = (const char *)P.wpack + lw * 1024;
-        auto dma_a = [&](int kstep, int slot) {                // k-step of the periodic 36-step stream -> ring slot
-            pn_glds16_s<0>(wsrc0 + (size_t)kstep * BB_ASLOT, lane16, (unsigned)(BB_OFF_A + slot * BB_ASLOT) + (unsigned)__builtin_amdgcn_readfirstlane(lw * 1024));
-        };
-        auto dma_in = [&](int t, int buf, int j) {             // piece n = lw * 12 + j of tile t's input image -> IN[buf]
+        int t = blockIdx.x;
+        if (t >= P.ntiles) return;
+        if (lw < 2) {
+            // ---- weight loaders: each fetches half (two 1 KB instructions) of both k-steps of a phase ----
+            // Ring of 6 slots, k-step k in slot k % 6; the compute waves read the fragments of k-step k during k - 1.  In phase q
+            // (k-steps 2q, 2q + 1) the loaders issue k-step 2q + 4 and then 2q + 5 into the slots phase q - 1 has just released;
+            // 2q + 4 is read in phase q + 1 and must have landed by the barrier that ends phase q (vmcnt leaves only the two
+            // newer instructions = 2q + 5 in flight), 2q + 5 is read in phase q + 2 and gets a phase of slack.
+            const char *wsrc = (const char *)P.wpack + lw * 2048;
+            auto dma_a = [&](int kstep) {                        // this wave's half of a k-step of the periodic 36-step stream
+                pn_glds16_s<0>(wsrc + (size_t)kstep * BB_ASLOT, lane16, (unsigned)(BB_OFF_A + (kstep % BB_NSLOT) * BB_ASLOT) + (unsigned)__builtin_amdgcn_readfirstlane(lw * 2048));
+                pn_glds16_s<0>(wsrc + (size_t)kstep * BB_ASLOT + 1024, lane16, (unsigned)(BB_OFF_A + (kstep % BB_NSLOT) * BB_ASLOT + 1024) + (unsigned)__builtin_amdgcn_readfirstlane(lw * 2048));
+            };
+            dma_a(0); dma_a(1); dma_a(2); dma_a(3);             // phases 0 and 1
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");              // (the compute waves have read k-step 0's fragments)
+            for (; t < P.ntiles; t += gridDim.x) {
+#pragma clang loop unroll(full)
+                for (int p = 0; p < 18; ++p) {                   // phase p = k-steps 2p, 2p + 1 of the tile's 36
+#ifndef BB_FAKE_NODMA_A
+                    dma_a((2 * p + 4) % 36);
+                    dma_a((2 * p + 5) % 36);
+                    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+#else
+                    asm volatile("s_barrier" ::: "memory");
+#endif
+                    if (p == 8) asm volatile("s_barrier" ::: "memory");          // the compute waves publish the intermediate image
+                }
+                asm volatile("s_barrier" ::: "memory");                             // end of tile
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        // ---- image loaders: wave 6 / 7 fetches pieces 0..23 / 24..47 of the NEXT tile's input image, two per phase ----
+        auto dma_in = [&](int tt, int buf, int n) {            // piece n = (quarter n / 12, halo row n % 12): 32 pixels x 32 B
             int b, oy0, ox0, R, Wc;
-            tile_geom(t, b, oy0, ox0, R, Wc);
-            const int n = lw * 12 + j;                        // quarter lw, halo row j: 32 pixels x 32 B
+            tile_geom(tt, b, oy0, ox0, R, Wc);
             const int qu = n / 12, row = n % 12;
             const int px = lane >> 1;
             const int iy = oy0 - 2 + row, ix = ox0 - 2 + px;
@@ -89,36 +121,25 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             const unsigned off = inb ? (unsigned)((iy * W + ix) * P.in_cs * 2 + qu * 32 + (lane & 1) * 16) : P.in_zero_off - (unsigned)frame_b;
             pn_glds16_s<0>((const char *)P.in + frame_b, off, (unsigned)__builtin_amdgcn_readfirstlane(buf * BB_IN + qu * BB_INQ + row * 1024));
         };
-        int t = blockIdx.x;
-        if (t >= P.ntiles) return;
+        const int n0 = (lw - 2) * 24;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) dma_in(t, 0, j);
-        dma_a(0, 0); dma_a(1, 1); dma_a(2, 2);
+        for (int j = 0; j < 24; ++j) dma_in(t, 0, n0 + j);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");              // the compute waves have read k-step 0's fragments: ring slot 0 may be refilled
+        asm volatile("s_barrier" ::: "memory");
         int cur = 0;
         for (; t < P.ntiles; t += gridDim.x) {
             const int tn = t + (int)gridDim.x < P.ntiles ? t + (int)gridDim.x : t;      // past the last tile: a harmless refetch into the idle image
 #pragma clang loop unroll(full)
-            for (int ph = 0; ph < 36; ++ph) {
-#ifndef BB_FAKE_NODMA_IN                               // -DBB_FAKE_*: timing-only ablations (wrong results), scripts/bblab.hip
-                if (ph < 12) dma_in(tn, cur ^ 1, ph);
+            for (int p = 0; p < 18; ++p) {
+#ifndef BB_FAKE_NODMA_IN
+                if (p < 12) { dma_in(tn, cur ^ 1, n0 + 2 * p); dma_in(tn, cur ^ 1, n0 + 2 * p + 1); }
 #endif
-#ifndef BB_FAKE_NODMA_A
-                dma_a((ph + 3) % 36, (ph + 3) % BB_NSLOT);
-#endif
-#if defined(BB_FAKE_NODMA_IN) || defined(BB_FAKE_NODMA_A)
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-                if (ph < 12) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
-#endif
-                if (ph == 17) asm volatile("s_barrier" ::: "memory");          // the compute waves publish the intermediate image
+                asm volatile("s_barrier" ::: "memory");
+                if (p == 8) asm volatile("s_barrier" ::: "memory");
             }
-            asm volatile("s_barrier" ::: "memory");                             // end of tile: residual reads of IN[cur] are done
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");             // end of tile: the next image is complete
             cur ^= 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
 
@@ -186,8 +207,9 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // (no lgkmcnt wait: the ring slot refilled after this barrier was last read a phase ago, the images are stable)
-            asm volatile("s_barrier" ::: "memory");
+            // one barrier per two k-steps (no lgkmcnt wait: the ring slots refilled after it were last read a phase ago, the
+            // images are stable)
+            if (ph & 1) asm volatile("s_barrier" ::: "memory");
         }
         if (it == 2) PN_STAMP_AT(2);
         // ---------------- intermediate: bias + ReLU -> bf16 -> LDS image (zero outside the map) ----------------
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
+            if (ph & 1) asm volatile("s_barrier" ::: "memory");
         }
         if (it == 2) PN_STAMP_AT(4);
         // ---------------- output: bias + residual (centre of the input image) + ReLU, 2 x 16-B stores per pixel ----------------
