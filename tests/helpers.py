@@ -121,3 +121,59 @@ def sample_indices(name, numel, n=48):
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     return np.sort(rng.choice(numel, size=min(n, numel), replace=False))
+
+
+# ---- engines against the CPU oracle, end to end (tests/test_gpu_precision.py, scripts/experiments/oracle_fidelity.py) ----
+def _oracle_signature(ref):
+    """(peak count, person -> peak-id table) of one oracle frame: what 'bit-exact person assignment' compares."""
+    assoc = np.asarray(ref["assoc"]).reshape(-1, 17)
+    return len(ref["joint_list"]), assoc[:, :15].astype(np.int32)
+
+
+def oracle_records(depth, state_dict, perturb=4, eps=1e-5, seed=0):
+    """The reference's CPU path (oracle: preproc + torch-CPU fp32 forward + NumPy parse) on `depth` [N, 640, 480] f16.
+    Returns one dict per frame: the oracle's records plus `fragile` -- True when the ORACLE's own person assignment changes
+    under one of `perturb` random relative perturbations of size `eps` of its fp32 maps (1e-5 = the difference between two
+    fp32 summation orders of these convolutions): a frame that holds a decision (a cell against the 0.1 threshold, two
+    neighbouring cells against each other, a limb score against 0.05) inside float32's own noise."""
+    from oracle import nets as onets, parse_paf as oparse, preproc as opre
+    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+    out = []
+    rng = np.random.default_rng(seed)
+    for s in range(0, len(depth), 32):
+        x = torch.from_numpy(opre.preprocess_batch(depth[s:s + 32]))
+        paf, heat, z = (a.numpy().transpose(0, 2, 3, 1) for a in onets.rtpose_light3d_forward(x, sd))
+        for b in range(len(x)):
+            ref = oparse.frame_to_records(heat[b].copy(), paf[b].copy(), z[b].copy())
+            n0, a0 = _oracle_signature(ref)
+            fragile = False
+            for _ in range(perturb):
+                hp = (heat[b] * (1 + eps * rng.standard_normal(heat[b].shape))).astype(np.float32)
+                pp = (paf[b] * (1 + eps * rng.standard_normal(paf[b].shape)) + eps * rng.standard_normal(paf[b].shape)).astype(np.float32)
+                alt = oparse.frame_to_records(hp, pp, z[b].copy())
+                n1, a1 = _oracle_signature(alt)
+                if n1 != n0 or a1.shape != a0.shape or not np.array_equal(a1, a0):
+                    fragile = True
+                    break
+            ref["fragile"] = fragile
+            out.append(ref)
+    return out
+
+
+def vs_oracle(recs, refs):
+    """pn_pose_frame records (numpy) of an engine against oracle_records(): frames with identical assignment, the largest 3D /
+    confidence difference on those, the differing frames and whether each of them is a fragile one."""
+    same, differing, d3, dc = 0, [], [0.0], [0.0]
+    for i, (r, ref) in enumerate(zip(recs, refs)):
+        n0, a0 = _oracle_signature(ref)
+        n = int(r["n_persons"])
+        if int(r["status"]) or n != a0.shape[0] or int(r["n_peaks"]) != n0 or not np.array_equal(r["person_joint"][:n], a0):
+            differing.append(i)
+            continue
+        same += 1
+        if n:
+            vis = r["person_joint"][:n] >= 0
+            d3.append(float(np.abs(r["joints_3d"][:n] - np.array(ref["humans_3d"]))[vis].max()) if vis.any() else 0.0)
+            dc.append(float(np.abs(r["part_conf"][:n] - np.array(ref["conf"]))[vis].max()) if vis.any() else 0.0)
+    return {"frames": len(refs), "same_assignment": same, "differing": differing, "fragile": sum(bool(f["fragile"]) for f in refs),
+            "differing_all_fragile": all(refs[i]["fragile"] for i in differing), "d3_m_max": max(d3), "conf_max": max(dc)}

@@ -1,7 +1,9 @@
 """Precision modes of the conv stack against north_star's tolerance (joints within 1e-3 m, person assignment bit-exact).
 
-fp32 (parity mode) is pinned against the reference itself in test_gpu_parity.py.  Here the other modes are measured
-against the fp32 engine, end to end, on 96 frames of the bench workload and on BOTH synthetic weight sets:
+fp32 (parity mode) is pinned against the reference itself in test_gpu_parity.py.  Round 3: both tolerance-meeting modes
+(fp32 and bf16x3) are also pinned against the CPU ORACLE end to end on 96 + 96 frames (test_engines_vs_cpu_oracle_end_to_end),
+not only against each other.  The other tests measure the modes against the fp32 engine on 96 frames of the bench workload and
+on BOTH synthetic weight sets:
   * threshold-calibrated   heat values crowd the 0.1 detection threshold (calibrate_heads, gain 1): the worst case for
                            a reduced-precision forward -- any logit error flips a peak;
   * comfortably separated  the same weights with the heat logits spread 6x before calibration.
@@ -45,10 +47,13 @@ def test_bf16_deviation_is_what_the_docs_say(gpu, gain):
     from popnet_amd.fidelity import compare_engines
     ref, eng = _engines(gpu, "bf16", gain)
     r = compare_engines(ref, eng, n_frames=96)
-    # throughput mode: NOT within 1e-3 m; pinned so that a regression (or an improvement) shows up
+    # throughput mode: NOT within 1e-3 m; pinned to the measured figures +- 10 % (bench.py prints the same ones under "fidelity"),
+    # so that a regression -- or an improvement -- of the headline mode's fidelity shows up
+    want = {1.0: {"same_person_count": 81, "same_assignment": 29, "d3_m_median": 1.736e-3, "d3_m_p95": 9.79e-3, "d3_m_max": 3.0e-2},
+            6.0: {"same_person_count": 79, "same_assignment": 27, "d3_m_median": 2.174e-3, "d3_m_p95": 1.317e-2, "d3_m_max": 5.31e-2}}[gain]
     assert r["frames"] == 96
-    assert r["same_person_count"] >= 60, r                 # measured: 81 / 79 of 96 (threshold-calibrated / spread weights)
-    assert r["d3_m_median"] < 5e-3 and r["d3_m_p95"] < 5e-2, r
+    for k, v in want.items():
+        assert 0.9 * v <= r[k] <= 1.1 * v + (1 if isinstance(v, int) else 0), (k, r[k], v, r)
 
 
 def test_bf16x3_forward_maps_vs_reference_golden(gpu, golden):
@@ -77,6 +82,59 @@ def test_bf16x3_yolo_forward_vs_reference_golden(gpu, golden):
     out = m(torch.from_numpy(g["x"]).to(gpu))
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy() - g["yolo_out"]).max() < 5e-3      # activations reach |x| ~ 150 with these weights (fp32 mode: 2e-3)
+
+
+@pytest.mark.parametrize("gain", [1.0, 6.0])
+def test_engines_vs_cpu_oracle_end_to_end(gpu, gain):
+    """The two tolerance-meeting modes against the ORACLE (preproc + torch-CPU fp32 forward + NumPy parse = the reference's CPU
+    path), not against each other, on 96 frames per weight set.
+      fp32 engine   identical person assignment in EVERY frame of both sets, 3D joints within 1e-3 m (measured 1.1e-5).
+      bf16x3        3D within 1e-3 m (measured 1.0e-4); assignment identical in all but <= 2 frames per set, and for every
+                    differing frame the difference is accounted for: the ORACLE's parse of the engine's own maps reproduces the
+                    engine's record bit for bit (the parse is exact) and those maps are within the forward tolerance (5e-4) of
+                    the oracle's -- i.e. a decision of that frame lies inside the forward's 16-significant-bit noise, nothing
+                    else differs.  (On a trained checkpoint no such frame exists: test_gpu_train.py::
+                    test_trained_checkpoint_bf16x3_equals_fp32_on_every_held_out_frame.)"""
+    from helpers import oracle_records, vs_oracle
+    from popnet_amd import synth
+    from popnet_amd.pipeline import PoseEngine, records_to_numpy
+    from popnet_amd.utils.paf_to_pose import frame_joint_list
+    from oracle import nets as onets, parse_paf as oparse, preproc as opre
+    n = 96
+    depth = np.concatenate([synth.synth_depth(32, 640, 480, seed=500 + s) for s in range(3)])
+    ref_eng, x3 = _engines(gpu, "bf16x3", gain)
+    sd = {k: v.detach().cpu() for k, v in ref_eng.model.state_dict().items()}
+    refs = oracle_records(depth, sd, perturb=0)
+    out = {}
+    for name, eng in (("fp32", ref_eng), ("bf16x3", x3)):
+        recs, maps = [], []
+        for i in range(0, n, 32):
+            recs.append(records_to_numpy(eng.predict(torch.from_numpy(depth[i:i + 32]).to(gpu))).copy())
+            maps.append([t[:32].cpu().numpy().transpose(0, 2, 3, 1).copy() for t in (eng.heat, eng.paf, eng.z)])
+        recs = np.concatenate(recs)
+        r = out[name] = vs_oracle(recs, refs)
+        assert r["frames"] == n and r["d3_m_max"] < 1e-3 and r["conf_max"] < 1e-3, (name, r)
+        if name == "fp32":
+            assert r["same_assignment"] == n, (name, r)            # the parity mode equals the reference's CPU path in every frame
+            continue
+        assert r["same_assignment"] >= n - 2, (name, r)            # measured: 95 / 94 of 96
+        x = torch.from_numpy(opre.preprocess_batch(depth))
+        for i in r["differing"]:
+            heat, paf, z = (m[i % 32] for m in maps[i // 32])
+            o_paf, o_heat, o_z = (a.numpy().transpose(0, 2, 3, 1)[0] for a in onets.rtpose_light3d_forward(x[i:i + 1], sd))
+            dmap = max(float(np.abs(heat - o_heat).max()), float(np.abs(paf - o_paf).max()), float(np.abs(z - o_z).max()))
+            assert dmap < 5e-4, (i, dmap)                            # the forward is within its tolerance on that frame ...
+            own = oparse.frame_to_records(heat.copy(), paf.copy(), z.copy())
+            jl = frame_joint_list(recs[i])
+            assert int(recs[i]["n_peaks"]) == len(own["joint_list"]) and (jl.size == 0 or np.array_equal(jl, own["joint_list"]))
+            oa = np.asarray(own["assoc"]).reshape(-1, 17)                                        # ... and the parse of those maps is exact
+            npers = int(recs[i]["n_persons"])
+            assert npers == oa.shape[0]
+            if npers:
+                assert np.array_equal(recs[i]["person_joint"][:npers], oa[:, :15].astype(np.int32))
+                assert np.array_equal(recs[i]["joints_3d"][:npers], np.array(own["humans_3d"]))
+    print("gain %.0f: fp32 engine == oracle in %d/%d frames, bf16x3 in %d/%d (d3 max %.3g / %.3g m)"
+          % (gain, out["fp32"]["same_assignment"], n, out["bf16x3"]["same_assignment"], n, out["fp32"]["d3_m_max"], out["bf16x3"]["d3_m_max"]))
 
 
 def test_fp32_engine_vs_cpu_oracle_noise_class(gpu):
