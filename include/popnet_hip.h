@@ -325,6 +325,15 @@ int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w,
                   int vis_margin, const pn_parse_cfg *glue /* may be NULL: input_size, w_org, h_org, intrinsics */,
                   pn_yolo_frame *frames_dev, void *hip_stream);
 
+/* pred_vis=True (prior_pose_align.py:62,120,153-157): the maps carry 5 + 4 J channels per anchor, the last J being predicted
+ * visibilities; vis_pred_dev [B][PN_YOLO_MAX_DET][J] float32 receives (in-bounds test) * (that channel), the value the
+ * reference returns as `visibility` in this mode.  Everything else as pn_parse_yolo. */
+int pn_parse_yolo_predvis(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w,
+                          const float *anchors_wh, int num_anchors, int num_joints, int w_out, int h_out,
+                          float depth_mean, float depth_std, float conf_threshold, float nms_threshold,
+                          int vis_margin, const pn_parse_cfg *glue, pn_yolo_frame *frames_dev, float *vis_pred_dev,
+                          void *hip_stream);
+
 size_t pn_sizeof_yolo_frame(void);
 
 /* Host-only diagnostic: the four float32 bicubic taps (OpenCV interpolateCubic, A = -0.75) the

@@ -61,11 +61,11 @@ def box_nms_keep(boxes, nms_threshold):
 
 
 def parse_prior_pose(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std,
-                     conf_threshold=0.35, nms_threshold=0.5, vis_margin=0):
-    """prior_pose_align.py:10-168 (pred_vis=False).  posemaps: float32 ndarray [B,A*(5+3J),h,w]
-    (the network output after its sigmoid casts).  Returns (bboxes, humans, visibility) as
-    nested lists like the reference: bboxes[b][n] float32[5], humans[b][n] float32[J,3],
-    visibility[b][n] bool[J]."""
+                     conf_threshold=0.35, nms_threshold=0.5, vis_margin=0, pred_vis=False):
+    """prior_pose_align.py:10-168.  posemaps: float32 ndarray [B,A*(5+3J),h,w] (the network output after its sigmoid
+    casts; [B,A*(5+4J),h,w] with pred_vis).  Returns (bboxes, humans, visibility) as nested lists like the reference:
+    bboxes[b][n] float32[5], humans[b][n] float32[J,3], visibility[b][n] bool[J] -- with pred_vis float32[J] =
+    the in-bounds test times the predicted visibility channel (:153-157)."""
     posemaps = np.asarray(posemaps, dtype=np.float32)
     if posemaps.ndim == 3:
         posemaps = posemaps[None]
@@ -100,9 +100,10 @@ def parse_prior_pose(posemaps, anchors, num_joints, w_out, h_out, depth_mean, de
         for box in boxes:
             human = box[5:5 + 3 * J].reshape(3, -1).T.copy()
             hb.append(human)
-            vb.append(np.logical_and(
+            inside = np.logical_and(
                 np.logical_and(human[:, 0] >= 0 + vis_margin, human[:, 0] <= w_out - 1 - vis_margin),
-                np.logical_and(human[:, 1] >= 0 + vis_margin, human[:, 1] <= h_out - 1 - vis_margin)))
+                np.logical_and(human[:, 1] >= 0 + vis_margin, human[:, 1] <= h_out - 1 - vis_margin))
+            vb.append(inside * box[5 + 3 * J:] if pred_vis else inside)
         humans_out.append(hb)
         vis_out.append(vb)
     return bboxes_out, humans_out, vis_out

@@ -177,7 +177,29 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
         if (m >= cin_ref)
             return pn_set_error(ctx, PN_ERR_INVALID, "%s: input-channel map exceeds Cin=%d", cs.w.c_str(), cin_ref);
     std::vector<int> wsel;                        // bf16x3: which half of the split weight multiplies this input channel (0 = hi, 1 = lo)
-    if (n->x3) {
+    // experiment switch (per-layer mixed precision inside a bf16x3 net): POPNET_X3_BF16_CONVS = comma-separated
+    // substrings of conv names that run as PLAIN bf16 -- they read only the hi plane of their input (one MFMA pass instead of
+    // three) and still write all three planes, so every other layer is unchanged
+    bool x3_low = false;
+    if (n->x3)
+        if (const char *e = getenv("POPNET_X3_BF16_CONVS")) {
+            std::string pats(e);
+            size_t pos = 0;
+            while (pos <= pats.size()) {
+                size_t c = pats.find(',', pos);
+                if (c == std::string::npos) c = pats.size();
+                const std::string pat = pats.substr(pos, c - pos);
+                if (!pat.empty() && cs.w.find(pat) != std::string::npos) x3_low = true;
+                pos = c + 1;
+            }
+        }
+    if (n->x3 && x3_low) {
+        const int pc = n->bufs[cs.in_buf].plane;
+        if (cs.in_coff != 0 || (int)map.size() > pc)
+            return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: bf16x3 convolutions read whole buffers", cs.w.c_str());
+        map.resize(pc, -1);
+        wsel.assign(pc, 0);
+    } else if (n->x3) {
         // the input is the WHOLE buffer, three planes of `plane` channels: [x_hi | x_lo | x_hi] against [W_hi | W_hi | W_lo]
         // = x_hi W_hi + x_lo W_hi + x_hi W_lo (the dropped x_lo W_lo term is 2^-16 of the product)
         const int pc = n->bufs[cs.in_buf].plane;

@@ -1,5 +1,5 @@
 // Yolo-Pose+ decode, greedy box NMS and skeleton extraction on the GPU -- replaces
-// parse_prior_pose (tpm/lib/utils/prior_pose_align.py:10-168, pred_vis=False), which the reference
+// parse_prior_pose (tpm/lib/utils/prior_pose_align.py:10-168, pred_vis False and True), which the reference
 // runs as a chain of small in-place torch ops plus a Python suppression loop per image.
 //
 // One workgroup per frame.  The network map ([A*(5+3J), h, w] f32, 78 KB at 14x14) is read once;
@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void parse_yolo_kernel(const float *__restrict
                                                           float w_out, float h_out, float depth_mean, float depth_std,
                                                           float conf_thr, float nms_thr, float vis_margin,
                                                           int glue, float g_in, float g_worg, float g_horg, float g_fx, float g_fy,
-                                                          float g_cx, float g_cy, pn_yolo_frame *__restrict__ frames) {
+                                                          float g_cx, float g_cy, pn_yolo_frame *__restrict__ frames,
+                                                          int F, float *__restrict__ vis_pred) {
     __shared__ unsigned short s_cell[YMAXC];            // candidate -> a*hw + cell
     __shared__ float s_score[YMAXC];
     __shared__ float s_x1[YMAXC], s_y1[YMAXC], s_x2[YMAXC], s_y2[YMAXC];   // in sorted order
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void parse_yolo_kernel(const float *__restrict
     __shared__ int s_wave_cnt[4];
     __shared__ int s_total;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hw = h * w, F = 5 + 3 * J, ncell = A * hw;
+    const int hw = h * w, ncell = A * hw;          // F = 5 + 3 J features per anchor, 5 + 4 J with predicted visibilities (pred_vis)
     const float *map = pm + (size_t)b * A * F * hw;
     pn_yolo_frame &out = frames[b];
     const float fw = (float)w, fh = (float)h;
@@ -172,8 +173,11 @@ __global__ __launch_bounds__(256) void parse_yolo_kernel(const float *__restrict
                         out.joints_3d[o][jn][1] = (y2 - g_cy) / g_fy * zz;
                         out.joints_3d[o][jn][2] = zz;
                     }
-                    out.visibility[o][jn] = (x >= 0.f + vis_margin && x <= w_out - 1.f - vis_margin &&
-                                             y >= 0.f + vis_margin && y <= h_out - 1.f - vis_margin) ? 1 : 0;
+                    const bool inside = x >= 0.f + vis_margin && x <= w_out - 1.f - vis_margin &&
+                                        y >= 0.f + vis_margin && y <= h_out - 1.f - vis_margin;
+                    out.visibility[o][jn] = inside ? 1 : 0;
+                    // pred_vis (:153-157): the in-bounds test TIMES the network's visibility channel (numpy bool * float32)
+                    if (vis_pred) vis_pred[((size_t)b * PN_YOLO_MAX_DET + o) * J + jn] = (inside ? 1.f : 0.f) * f[(size_t)(5 + 3 * J + jn) * hw];
                 }
             }
             n_out += __popcll(bal);
@@ -188,26 +192,45 @@ __global__ __launch_bounds__(256) void parse_yolo_kernel(const float *__restrict
     }
 }
 
-extern "C" int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w, const float *anchors_wh,
-                             int num_anchors, int num_joints, int w_out, int h_out, float depth_mean, float depth_std,
-                             float conf_threshold, float nms_threshold, int vis_margin, const pn_parse_cfg *glue,
-                             pn_yolo_frame *frames_dev, void *hip_stream) {
+static int parse_yolo_impl(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w, const float *anchors_wh,
+                           int num_anchors, int num_joints, int w_out, int h_out, float depth_mean, float depth_std,
+                           float conf_threshold, float nms_threshold, int vis_margin, const pn_parse_cfg *glue,
+                           pn_yolo_frame *frames_dev, float *vis_pred_dev, void *hip_stream, const char *who) {
     if (!ctx) return PN_ERR_INVALID;
     if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
-    if (!posemaps_dev || !anchors_wh || !frames_dev || B < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_parse_yolo: bad arguments");
-    if (num_anchors < 1 || num_anchors > 3) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_yolo: 1..3 anchors supported");
-    if (num_joints != PN_NUM_JOINTS) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_yolo: built for %d joints", PN_NUM_JOINTS);
-    if (num_anchors * h * w > YMAXC) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_yolo: %d cells exceed %d", num_anchors * h * w, YMAXC);
+    if (!posemaps_dev || !anchors_wh || !frames_dev || B < 1) return pn_set_error(ctx, PN_ERR_INVALID, "%s: bad arguments", who);
+    if (num_anchors < 1 || num_anchors > 3) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: 1..3 anchors supported", who);
+    if (num_joints != PN_NUM_JOINTS) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: built for %d joints", who, PN_NUM_JOINTS);
+    if (num_anchors * h * w > YMAXC) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: %d cells exceed %d", who, num_anchors * h * w, YMAXC);
     float a[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 2 * num_anchors; ++i) a[i] = anchors_wh[i];
     PN_HIP_CHECK(ctx, hipMemsetAsync(frames_dev, 0, (size_t)B * sizeof(pn_yolo_frame), (hipStream_t)hip_stream));   // unused rows read as zero
+    if (vis_pred_dev) PN_HIP_CHECK(ctx, hipMemsetAsync(vis_pred_dev, 0, (size_t)B * PN_YOLO_MAX_DET * PN_NUM_JOINTS * sizeof(float), (hipStream_t)hip_stream));
     hipLaunchKernelGGL(parse_yolo_kernel, dim3(B), dim3(256), 0, (hipStream_t)hip_stream, posemaps_dev, h, w, num_anchors,
                        num_joints, a[0], a[1], a[2], a[3], a[4], a[5], (float)w_out, (float)h_out, depth_mean, depth_std,
                        conf_threshold, nms_threshold, (float)vis_margin, glue ? 1 : 0, glue ? (float)glue->input_size : 1.f,
                        glue ? (float)glue->w_org : 1.f, glue ? (float)glue->h_org : 1.f, glue ? (float)glue->fx : 1.f,
-                       glue ? (float)glue->fy : 1.f, glue ? (float)glue->cx : 0.f, glue ? (float)glue->cy : 0.f, frames_dev);
+                       glue ? (float)glue->fy : 1.f, glue ? (float)glue->cx : 0.f, glue ? (float)glue->cy : 0.f, frames_dev,
+                       vis_pred_dev ? 5 + 4 * num_joints : 5 + 3 * num_joints, vis_pred_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
+}
+
+extern "C" int pn_parse_yolo(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w, const float *anchors_wh,
+                             int num_anchors, int num_joints, int w_out, int h_out, float depth_mean, float depth_std,
+                             float conf_threshold, float nms_threshold, int vis_margin, const pn_parse_cfg *glue,
+                             pn_yolo_frame *frames_dev, void *hip_stream) {
+    return parse_yolo_impl(ctx, posemaps_dev, B, h, w, anchors_wh, num_anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold,
+                           nms_threshold, vis_margin, glue, frames_dev, nullptr, hip_stream, "pn_parse_yolo");
+}
+
+extern "C" int pn_parse_yolo_predvis(pn_ctx *ctx, const float *posemaps_dev, int B, int h, int w, const float *anchors_wh,
+                                     int num_anchors, int num_joints, int w_out, int h_out, float depth_mean, float depth_std,
+                                     float conf_threshold, float nms_threshold, int vis_margin, const pn_parse_cfg *glue,
+                                     pn_yolo_frame *frames_dev, float *vis_pred_dev, void *hip_stream) {
+    if (!vis_pred_dev) return pn_set_error(ctx, PN_ERR_INVALID, "pn_parse_yolo_predvis: vis_pred_dev is required");
+    return parse_yolo_impl(ctx, posemaps_dev, B, h, w, anchors_wh, num_anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold,
+                           nms_threshold, vis_margin, glue, frames_dev, vis_pred_dev, hip_stream, "pn_parse_yolo_predvis");
 }
 
 extern "C" size_t pn_sizeof_pose_frame(void) { return sizeof(pn_pose_frame); }

@@ -65,8 +65,9 @@ class HipNetModule(nn.Module):
 
     def _compile(self, device, batch, in_h, in_w):
         if self.training:
-            raise _lib.PopnetError("popnet_amd: module.forward is the eval-mode inference path (call .eval()); a training step "
-                                   "(train-mode BatchNorm, loss, backward, SGD) is popnet_amd.train.TrainEngine.from_module(module).step(...)")
+            raise _lib.PopnetError("popnet_amd: the compiled (BN-folded, MFMA-packed) net is the eval-mode inference path -- call .eval(); in train "
+                                   "mode rtpose_light3d.forward runs the autograd-wrapped training primitives (network/_autograd.py), and "
+                                   "popnet_amd.train.TrainEngine.from_module(module).step(...) is the fast path for whole training steps")
         prec = _PREC.get(str(self.precision).lower())
         if prec is None:
             raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3', got %r" % (self.precision,))

@@ -81,7 +81,50 @@ class rtpose_light3d(HipNetModule):
     def _net_args(self):
         return self._kind, self.num_parts, self.num_limbs, self.input_dim
 
+    # ---- train mode: the reference's forward (rtpose_light3d.py:206-219, 326-356) on the autograd-wrapped HIP primitives ----
+    def _forward_train(self, x):
+        from . import _autograd as ag
+        x = self._check_input(x)
+        if x.shape[2] % 8 or x.shape[3] % 8:
+            raise _lib.PopnetError("input size must be a multiple of 8")
+        for p in self.parameters():
+            if p.device != x.device:
+                raise _lib.PopnetError("popnet_amd: module parameters are on %s, the input on %s -- call model.cuda() (the HIP path has no CPU fallback)" % (p.device, x.device))
+
+        def block(u, a):                       # BasicBlock (rtpose_light3d.py:36-72)
+            y = ag.bn_act(ag.conv(a, u.conv1), u.bn1, ag.ACT_RELU)
+            y = ag.conv(y, u.conv2)
+            idn = a if u.downsample is None else ag.bn_act(ag.conv(a, u.downsample[0]), u.downsample[1], ag.ACT_NONE)
+            return ag.bn_act(y, u.bn2, ag.ACT_RELU, res=idn)
+
+        def branch(seq, a):                    # make_stages Sequential (:222-246)
+            for i in (0, 3, 6, 9):
+                a = ag.bn_act(ag.conv(a, seq[i]), seq[i + 1], ag.ACT_LEAKY)
+            return ag.conv(a, seq[12])
+
+        m0 = self.model0
+        a = ag.bn_act(ag.conv(x, m0.conv1), m0.bn1, ag.ACT_RELU)
+        for u in m0.layer1:
+            a = block(u, a)
+        a = ag.avgpool(a)
+        for u in m0.layer2:
+            a = block(u, a)
+        a = ag.bn_act(ag.conv(a, m0.conv2), m0.bn2, ag.ACT_RELU)
+        out1 = ag.avgpool(a)
+        # the range casts of :335-337 / :347-349 and the concat of :339 are element-wise glue: left to torch (autograd orders them)
+        out1_1 = (branch(self.model1_1, out1).sigmoid() - 0.5) * 4
+        out1_2 = branch(self.model1_2, out1).sigmoid()
+        out1_3 = (branch(self.model1_3, out1).sigmoid() - 0.5) * 4
+        out2 = torch.cat([out1_1, out1_2, out1_3, out1], 1)
+        out2_1 = (branch(self.model2_1, out2).sigmoid() - 0.5) * 4
+        out2_2 = branch(self.model2_2, out2).sigmoid()
+        out2_3 = (branch(self.model2_3, out2).sigmoid() - 0.5) * 4
+        self.invalidate()                      # the weights are about to change: the eval-mode net is re-folded on its next use
+        return (out2_1, out2_2, out2_3), [out1_1, out1_2, out1_3, out2_1, out2_2, out2_3]
+
     def forward(self, x):
+        if self.training:
+            return self._forward_train(x)
         x = self._check_input(x)
         B, _, H, W = x.shape
         dev = x.device

@@ -1,7 +1,8 @@
 """``parse_prior_pose`` with the reference's signature, computed on the GPU.
 
-Drop-in for tpm/lib/utils/prior_pose_align.py:10-168 (pred_vis=False): same arguments, same
-return structure ``(bboxes[B][n] float32[5], humans[B][n] float32[J,3], visibility[B][n] bool[J])``.
+Drop-in for tpm/lib/utils/prior_pose_align.py:10-168: same arguments, same return structure
+``(bboxes[B][n] float32[5], humans[B][n] float32[J,3], visibility[B][n] bool[J])``; with pred_vis=True the maps carry
+5 + 4 J channels per anchor and ``visibility`` is float32[J] = in-bounds test x predicted visibility (:153-157).
 One HIP workgroup per image decodes only the cells above the objectness threshold, sorts, builds
 the IoU conflict matrix and runs the reference's suppression loop (csrc/parse_yolo.hip).
 Unlike the reference, ``posemaps`` is NOT modified in place (calling the reference twice on the
@@ -16,7 +17,7 @@ from .. import _lib
 
 
 def parse_yolo_batch(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold,
-                     nms_threshold, vis_margin=0, glue_cfg=None, frames=None):
+                     nms_threshold, vis_margin=0, glue_cfg=None, frames=None, vis_pred=None):
     """posemaps: float32 CUDA tensor [B, A*(5+3J), h, w].  Returns host records (structured array), or --
     when a device `frames` buffer is given -- leaves them on the device (no synchronisation).  glue_cfg
     (a _lib.ParseCfg) additionally fills joints_2d / joints_3d / bbox_org like the evaluation script."""
@@ -32,11 +33,18 @@ def parse_yolo_batch(posemaps, anchors, num_joints, w_out, h_out, depth_mean, de
     flat = [float(v) for a in anchors for v in a]
     arr = (C.c_float * len(flat))(*flat)
     ctx = _lib.Context.for_device(dev.index)
-    ctx.check(_lib.lib().pn_parse_yolo(ctx.handle, C.c_void_p(pm.data_ptr()), B, h, w, arr, len(anchors), num_joints,
-                                       int(w_out), int(h_out), float(depth_mean), float(depth_std), float(conf_threshold),
-                                       float(nms_threshold), int(vis_margin), C.byref(glue_cfg) if glue_cfg is not None else None,
-                                       C.c_void_p(frames.data_ptr()),
-                                       _lib.current_stream_ptr(dev)), "pn_parse_yolo")
+    want_c = len(anchors) * (5 + (4 if vis_pred is not None else 3) * num_joints)
+    if pm.shape[1] != want_c:
+        raise _lib.PopnetError("posemaps has %d channels, %d anchors x (5 + %d x %d joints) = %d expected"
+                               % (pm.shape[1], len(anchors), 4 if vis_pred is not None else 3, num_joints, want_c))
+    args = (ctx.handle, C.c_void_p(pm.data_ptr()), B, h, w, arr, len(anchors), num_joints,
+            int(w_out), int(h_out), float(depth_mean), float(depth_std), float(conf_threshold),
+            float(nms_threshold), int(vis_margin), C.byref(glue_cfg) if glue_cfg is not None else None,
+            C.c_void_p(frames.data_ptr()))
+    if vis_pred is not None:         # [B, PN_YOLO_MAX_DET, J] float32 device tensor
+        ctx.check(_lib.lib().pn_parse_yolo_predvis(*args, C.c_void_p(vis_pred.data_ptr()), _lib.current_stream_ptr(dev)), "pn_parse_yolo_predvis")
+    else:
+        ctx.check(_lib.lib().pn_parse_yolo(*args, _lib.current_stream_ptr(dev)), "pn_parse_yolo")
     if keep_on_device:
         return frames[:B]
     return frames.cpu().numpy().view(_lib.YOLO_FRAME_DTYPE).reshape(B)
@@ -44,10 +52,13 @@ def parse_yolo_batch(posemaps, anchors, num_joints, w_out, h_out, depth_mean, de
 
 def parse_prior_pose(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold=0.35,
                      nms_threshold=0.5, pred_vis=False, vis_margin=0):
+    vis_pred = None
     if pred_vis:
-        raise _lib.PopnetError("pred_vis=True (4J-channel maps) is not part of the MP-3DHP path and is not built")
+        B = 1 if posemaps.dim() == 3 else posemaps.shape[0]
+        vis_pred = torch.empty((B, _lib.PN_YOLO_MAX_DET, num_joints), device=posemaps.device, dtype=torch.float32)
     recs = parse_yolo_batch(posemaps, anchors, num_joints, w_out, h_out, depth_mean, depth_std, conf_threshold,
-                            nms_threshold, vis_margin)
+                            nms_threshold, vis_margin, vis_pred=vis_pred)
+    vp = vis_pred.cpu().numpy() if pred_vis else None
     bboxes_out, humans_prior, visibility = [], [], []
     for fr in recs:
         if int(fr['status']):
@@ -58,5 +69,8 @@ def parse_prior_pose(posemaps, anchors, num_joints, w_out, h_out, depth_mean, de
             continue
         bboxes_out.append([fr['bbox'][i].copy() for i in range(n)])
         humans_prior.append([fr['human'][i].copy() for i in range(n)])
-        visibility.append([fr['visibility'][i].astype(bool) for i in range(n)])
+        if pred_vis:
+            visibility.append([vp[len(visibility)][i].copy() for i in range(n)])
+        else:
+            visibility.append([fr['visibility'][i].astype(bool) for i in range(n)])
     return bboxes_out, humans_prior, visibility

@@ -251,6 +251,17 @@ def yolo_maps(seed, B=2, clusters=True):
     return pm
 
 
+def yolo_maps_predvis(seed, B=2):
+    """[B, 2 x (5 + 4 x 15), 14, 14]: yolo_maps() with 15 predicted-visibility channels appended to every anchor."""
+    base = yolo_maps(seed, B)
+    rng = np.random.default_rng(seed + 1000)
+    pm = np.zeros((B, 130, 14, 14), np.float32)
+    for a in (0, 1):
+        pm[:, 65 * a:65 * a + 50] = base[:, 50 * a:50 * a + 50]
+        pm[:, 65 * a + 50:65 * a + 65] = rng.uniform(0.0, 1.0, (B, 15, 14, 14))
+    return pm
+
+
 def golden_yolo():
     import torch
     from lib.utils.prior_pose_align import parse_prior_pose
@@ -263,6 +274,14 @@ def golden_yolo():
             out["s%d_%d_human" % (seed, i)] = np.array(h[i], dtype=np.float32).reshape(-1, 15, 3)
             out["s%d_%d_vis" % (seed, i)] = np.array(v[i], dtype=bool).reshape(-1, 15)
             print("F3 seed %d img %d: %d boxes" % (seed, i, len(b[i])))
+    # pred_vis=True (:62,120,153-157): 5 + 4 J channels per anchor, visibility = in-bounds test x predicted visibility
+    pm = yolo_maps_predvis(34)
+    b, h, v = parse_prior_pose(torch.from_numpy(pm.copy()), [(6., 3.), (12., 6.)], 15, 224, 224, 3, 2, 0.5, 0.5, pred_vis=True)
+    for i in range(pm.shape[0]):
+        out["pv_%d_bbox" % i] = np.array(b[i], dtype=np.float32).reshape(-1, 5)
+        out["pv_%d_human" % i] = np.array(h[i], dtype=np.float32).reshape(-1, 15, 3)
+        out["pv_%d_vis" % i] = np.array(v[i], dtype=np.float32).reshape(-1, 15)
+        print("F3 pred_vis img %d: %d boxes" % (i, len(b[i])))
     np.savez_compressed(os.path.join(OUT, "parse_yolo.npz"), **out)
 
 

@@ -58,6 +58,18 @@ def yolo_maps(seed, B=2, clusters=True):
     return pm
 
 
+def yolo_maps_predvis(seed, B=2):
+    """[B, 2 x (5 + 4 x 15), 14, 14]: yolo_maps() with 15 predicted-visibility channels appended to every anchor (same
+    generator as tests/golden/make_golden.py)."""
+    base = yolo_maps(seed, B)
+    rng = np.random.default_rng(seed + 1000)
+    pm = np.zeros((B, 130, 14, 14), np.float32)
+    for a in (0, 1):
+        pm[:, 65 * a:65 * a + 50] = base[:, 50 * a:50 * a + 50]
+        pm[:, 65 * a + 50:65 * a + 65] = rng.uniform(0.0, 1.0, (B, 15, 14, 14))
+    return pm
+
+
 def coco_case(seed, P, H=184, W=216):
     rng = np.random.default_rng(seed)
     pairs = [(1, 2), (1, 5), (2, 3), (3, 4), (5, 6), (6, 7), (1, 8), (8, 9), (9, 10), (1, 11), (11, 12), (12, 13), (1, 0),

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from helpers import (PAFPROCESS_CASES, YOLO_ANCHORS, all_parse_case_names, coco_case, humans_to_array,
-                     parse_case_inputs, state_dict_from_keys, yolo_maps)
+                     parse_case_inputs, state_dict_from_keys, yolo_maps, yolo_maps_predvis)
 from oracle import cv2_resize, nets, parse_paf, parse_yolo, preproc
 from popnet_amd import synth
 
@@ -103,6 +103,19 @@ def test_script_level_pipeline_matches_reference_eval_script(golden):
         assert np.allclose(np.array(rec["humans_2d"]).reshape(-1, 15, 2), np.array(s["human_pred_set_2d"][b]).reshape(-1, 15, 2), atol=1e-9)
         assert np.allclose(np.array(rec["humans_3d"]).reshape(-1, 15, 3), np.array(s["human_pred_set_3d"][b]).reshape(-1, 15, 3), atol=1e-5)
         assert np.allclose(np.array(rec["conf"]).reshape(-1, 15), np.array(s["human_pred_set_part_conf"][b]).reshape(-1, 15), atol=1e-6)
+
+
+def test_yolo_decode_pred_vis_matches_reference(golden):
+    """pred_vis=True (prior_pose_align.py:62,120,153-157): 5 + 4 J channels per anchor, visibility = in-bounds test x channel."""
+    pm = yolo_maps_predvis(34)
+    b, h, v = parse_yolo.parse_prior_pose(pm, YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5, pred_vis=True)
+    total = 0
+    for i in range(pm.shape[0]):
+        assert np.array_equal(np.array(b[i], np.float32).reshape(-1, 5), golden.yolo["pv_%d_bbox" % i])
+        assert np.array_equal(np.array(h[i], np.float32).reshape(-1, 15, 3), golden.yolo["pv_%d_human" % i])
+        assert np.array_equal(np.array(v[i], np.float32).reshape(-1, 15), golden.yolo["pv_%d_vis" % i])
+        total += len(b[i])
+    assert total >= 4
 
 
 def test_yolo_script_level_pipeline_matches_reference_eval_script(golden):
