@@ -188,6 +188,18 @@ int pn_parse_paf(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const
  * captured, and after pn_parse_reserve has fixed the size.                                                          */
 int pn_parse_reserve(pn_ctx *ctx, int max_batch);
 
+/* The same parse WITHOUT the record capacities (the reference has none): one frame (heat [J+1,h,w], paf [2L,h,w], z [L+1,h,w]
+ * device maps), every list in a workspace sized from the frame's own counts (up to h*w peaks per joint map).  The second pass
+ * for a frame whose fixed-size record carries PN_FRAME_OVERFLOW_*: same arithmetic, same order, variable-length result.
+ * Synchronises the stream; *n_peaks / *n_persons size the arrays pn_parse_paf_unbounded_fetch copies out (any of them may be
+ * NULL): peaks_xys [n_peaks][3] (x, y, score; id = row, as paf_to_pose's joint_list), peak_type [n_peaks], person_joint
+ * [n_persons][J], person_score / person_count [n_persons], joints_2d [n][J][2], joints_3d [n][J][3], part_conf [n][J].
+ * The result lives in the context until the next pn_parse_paf_unbounded call (not re-entrant per context). */
+int pn_parse_paf_unbounded(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev, int h, int w,
+                           const pn_parse_cfg *cfg, int *n_peaks, int *n_persons, void *hip_stream);
+int pn_parse_paf_unbounded_fetch(pn_ctx *ctx, float *peaks_xys, int *peak_type, int *person_joint, double *person_score,
+                                 int *person_count, double *joints_2d, double *joints_3d, double *part_conf);
+
 /* retrieve_depth_heat_weighted(center, depthmap, heatmap, radius) (tpm/lib/utils/common.py:272-293)
  * for n centres (x, y int32 pairs) on one [h, w] f32 map pair; like the reference it first clamps
  * negative heat values in place.  out_dev: n float32 (the reference's np.sum/np.sum is float32).   */

@@ -120,6 +120,8 @@ _SIGNATURES = {
     "pn_sgd_nesterov": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _i, _f, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),
+    "pn_parse_paf_unbounded": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(ParseCfg), C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
+    "pn_parse_paf_unbounded_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pn_parse_yolo_predvis": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp, _vp]),
     "pn_sizeof_pose_frame": (_sz, []),
     "pn_pack_pose_frames": (_i, [_vp, _vp, _i, _vp, _vp]),

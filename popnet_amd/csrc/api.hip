@@ -79,6 +79,7 @@ pn_ctx *pn_create(int device_id) {
 void pn_destroy(pn_ctx *ctx) {
     if (!ctx) return;
     if (ctx->parse_ws) (void)hipFree(ctx->parse_ws);
+    pn_parse_big_free(ctx);
     if (ctx->train_ws) (void)hipFree(ctx->train_ws);
     for (void *p : ctx->train_ws_retired) (void)hipFree(p);
     delete ctx;

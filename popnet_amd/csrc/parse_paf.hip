@@ -26,6 +26,7 @@
 // pairwise summation order for np.mean / np.sum, round-half-even for np.round, and no fused
 // multiply-add anywhere in this file.
 #pragma clang fp contract(off)
+#include <algorithm>
 #include <cmath>
 #include "pn_internal.h"
 
@@ -628,6 +629,524 @@ extern "C" int pn_parse_reserve(pn_ctx *ctx, int max_batch) {
     }
     ctx->parse_ws_fixed = true;
     return PN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unbounded path: the same algorithm WITHOUT the record capacities (the reference has none: paf_to_pose.py:33-153,267-351).
+// One frame per call, every list in a global-memory workspace sized from the frame's own counts (up to h*w peaks per joint
+// map, min(ns, nd) connections per limb, one person per connection), results fetched as variable-length arrays.  It is the
+// second pass for a frame the fixed-size records flag as overflowing (PN_FRAME_OVERFLOW_*): slower (lists in L2 instead of
+// LDS, the greedy matching as repeated arg-max instead of a rank sort) but the same arithmetic in the same order, so a frame
+// that fits the records gives the same values through either path (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------
+struct BigWs {
+    int *peak_count;                 // [J]
+    float *px, *py, *ps;             // [J][hw]
+    int *conn_count;                 // [L]
+    int *conn_i, *conn_j;            // [L][hw]
+    double *conn_s;                  // [L][hw]
+    double *cand_s;                  // candidates of all limbs, limb l at cand_off[l]
+    unsigned short *cand_i, *cand_j;
+    long long cand_off[L_ + 1];
+    double *rows, *rows2;            // [maxp][J + 2]
+    int maxp;
+    int *keep_idx;                   // [maxp]
+    int *counts;                     // [0] peaks, [1] persons
+    // results
+    float *o_peak;                   // [npeaks][3]: x, y, score
+    int *o_peak_type;                // [npeaks]
+    int *o_person_joint;             // [P][J]
+    double *o_person_score;          // [P]
+    int *o_person_count;             // [P]
+    double *o_j2d, *o_j3d, *o_conf;  // [P][J][2], [P][J][3], [P][J]
+};
+
+__global__ __launch_bounds__(256) void big_peaks_kernel(const float *__restrict__ heat, int h, int w, float thresh, CubicTab tab, BigWs W) {
+    __shared__ float map[MAX_MAP];
+    __shared__ int s_wave_cnt[4];
+    __shared__ unsigned short s_wlist[4][MAX_MAP / 4 + 1];
+    __shared__ float s_h[4][5 * 40];
+    const int joint = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw = h * w;
+    const float *src = heat + (size_t)joint * hw;
+    for (int i = tid; i < hw; i += 256) map[i] = src[i];
+    __syncthreads();
+    {
+        const int Q = (hw + 3) / 4;
+        const int lo = wave * Q, hi = min(hw, lo + Q);
+        int wcnt = 0;
+        for (int base = lo; base < hi; base += 64) {
+            const int i = base + lane;
+            bool pk = false;
+            if (i < hi) {
+                const int y = i / w, x = i - y * w;
+                const float v = map[i];
+                float m = v;
+                if (y > 0) m = fmaxf(m, map[i - w]);
+                if (y < h - 1) m = fmaxf(m, map[i + w]);
+                if (x > 0) m = fmaxf(m, map[i - 1]);
+                if (x < w - 1) m = fmaxf(m, map[i + 1]);
+                pk = (m == v) && (v > thresh);
+            }
+            const unsigned long long bal = __ballot(pk);
+            const int pos = wcnt + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pk) s_wlist[wave][pos] = (unsigned short)i;
+            wcnt += __popcll(bal);
+        }
+        if (lane == 0) s_wave_cnt[wave] = wcnt;
+    }
+    __syncthreads();
+    const int c0 = s_wave_cnt[0], c1 = s_wave_cnt[1], c2 = s_wave_cnt[2];
+    const int total = c0 + c1 + c2 + s_wave_cnt[3];
+    if (tid == 0) W.peak_count[joint] = total;
+    float *opx = W.px + (size_t)joint * hw, *opy = W.py + (size_t)joint * hw, *ops = W.ps + (size_t)joint * hw;
+    for (int p = wave; p < total; p += 4) {
+        int cell;
+        if (p < c0) cell = s_wlist[0][p];
+        else if (p < c0 + c1) cell = s_wlist[1][p - c0];
+        else if (p < c0 + c1 + c2) cell = s_wlist[2][p - c0 - c1];
+        else cell = s_wlist[3][p - c0 - c1 - c2];
+        const int px = cell % w, py = cell / w;
+        const int x_min = max(0, px - 2), y_min = max(0, py - 2);
+        const int x_max = min(w - 1, px + 2), y_max = min(h - 1, py + 2);
+        const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;
+        const int uw = pw * 8, un = uw * ph * 8;
+        const float inv_uw = 1.0f / (float)uw;
+        const float *patch = map + y_min * w + x_min;
+        float *hb = s_h[wave];
+        for (int i = lane; i < ph * uw; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * inv_uw), ux = i - r * uw;
+            int sx0, phx;
+            up8_src(ux, sx0, phx);
+            const float *row = patch + r * w;
+            float hv = row[min(max(sx0, 0), pw - 1)] * tab.c[phx][0];
+            hv = hv + row[min(max(sx0 + 1, 0), pw - 1)] * tab.c[phx][1];
+            hv = hv + row[min(max(sx0 + 2, 0), pw - 1)] * tab.c[phx][2];
+            hv = hv + row[min(max(sx0 + 3, 0), pw - 1)] * tab.c[phx][3];
+            hb[r * 40 + ux] = hv;
+        }
+        WAVE_LDS_SYNC();
+        float best = -INFINITY;
+        int best_i = 0x7fffffff;
+        for (int i = lane; i < un; i += 64) {
+            const int uy = (int)(((float)i + 0.5f) * inv_uw), ux = i - uy * uw;
+            int sy0, phy;
+            up8_src(uy, sy0, phy);
+            float v = hb[min(max(sy0, 0), ph - 1) * 40 + ux] * tab.c[phy][0];
+            v = v + hb[min(max(sy0 + 1, 0), ph - 1) * 40 + ux] * tab.c[phy][1];
+            v = v + hb[min(max(sy0 + 2, 0), ph - 1) * 40 + ux] * tab.c[phy][2];
+            v = v + hb[min(max(sy0 + 3, 0), ph - 1) * 40 + ux] * tab.c[phy][3];
+            if (v > best || best_i == 0x7fffffff) { best = v; best_i = i; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            float ov = __shfl_xor(best, off);
+            int oi = __shfl_xor(best_i, off);
+            if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+        }
+        if (lane == 0) {
+            int my = (int)(((float)best_i + 0.5f) * inv_uw), mx = best_i - my * uw;
+            opx[p] = (float)(8 * x_min + mx);
+            opy[p] = (float)(8 * y_min + my);
+            ops[p] = best;
+        }
+        WAVE_LDS_SYNC();
+    }
+}
+
+__global__ __launch_bounds__(256) void big_limb_kernel(const float *__restrict__ paf, int h, int w, float thresh_paf, int up_h, CubicTab tab, BigWs W) {
+    __shared__ float pmap[2][MAX_MAP];
+    __shared__ double s_pts[PAIRS_PER_PASS][10];
+    __shared__ unsigned s_used_i[MAX_MAP / 32], s_used_j[MAX_MAP / 32];
+    __shared__ double s_best_s[256];
+    __shared__ int s_best_k[256];
+    __shared__ int s_ncand;
+    const int limb = blockIdx.x, tid = threadIdx.x;
+    const int jsrc = c_limb_src[limb], jdst = c_limb_dst[limb];
+    const int ns = W.peak_count[jsrc], nd = W.peak_count[jdst];
+    if (ns == 0 || nd == 0) {
+        if (tid == 0) W.conn_count[limb] = 0;
+        return;
+    }
+    const int hw = h * w;
+    const float *sx_ = W.px + (size_t)jsrc * hw, *sy_ = W.py + (size_t)jsrc * hw;
+    const float *dx_ = W.px + (size_t)jdst * hw, *dy_ = W.py + (size_t)jdst * hw;
+    double *cs = W.cand_s + W.cand_off[limb];
+    unsigned short *ci = W.cand_i + W.cand_off[limb], *cj = W.cand_j + W.cand_off[limb];
+    const float *px_map = paf + (size_t)(2 * limb) * hw;
+    for (int i = tid; i < hw; i += 256) {
+        pmap[0][i] = px_map[i];
+        pmap[1][i] = px_map[hw + i];
+    }
+    for (int i = tid; i < MAX_MAP / 32; i += 256) { s_used_i[i] = 0u; s_used_j[i] = 0u; }
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+    const long long npairs = (long long)ns * nd;
+    for (long long pbase = 0; pbase < npairs; pbase += PAIRS_PER_PASS) {
+        const int lp = tid / 10, pt = tid - lp * 10;
+        const long long pair = pbase + lp;
+        const bool active = lp < PAIRS_PER_PASS && pair < npairs;
+        if (active) {
+            const int i = (int)(pair / nd), j = (int)(pair - (long long)i * nd);
+            const double sx = (double)sx_[i], sy = (double)sy_[i];
+            const double ex = (double)dx_[j], ey = (double)dy_[j];
+            const double ddx = ex - sx, ddy = ey - sy;
+            const double dist = sqrt(ddx * ddx + ddy * ddy) + 1e-8;
+            const double dxn = ddx / dist, dyn = ddy / dist;
+            const double stepx = (ex - sx) / 9.0, stepy = (ey - sy) / 9.0;
+            const int qx = linspace_round(sx, ex, stepx, pt, 10);
+            const int qy = linspace_round(sy, ey, stepy, pt, 10);
+            const float vx = bicubic8(pmap[0], w, h, w, qy, qx, tab);
+            const float vy = bicubic8(pmap[1], w, h, w, qy, qx, tab);
+            s_pts[lp][pt] = (double)vx * dxn + (double)vy * dyn;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            bool ok = false;
+            double score = 0;
+            const long long pr = pbase + tid;
+            if (tid < PAIRS_PER_PASS && pr < npairs) {
+                const double *s = s_pts[tid];
+                double res = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+                res = res + s[8];
+                res = res + s[9];
+                const double mean = res / 10.0;
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) cnt += (s[k] > (double)thresh_paf) ? 1 : 0;
+                const int i = (int)(pr / nd), j = (int)(pr - (long long)i * nd);
+                const double ax = (double)sx_[i], ay = (double)sy_[i];
+                const double bx = (double)dx_[j], by = (double)dy_[j];
+                const double ddx = bx - ax, ddy = by - ay;
+                const double dd = sqrt(ddx * ddx + ddy * ddy) + 1e-8;
+                const double pen = fmin(0.5 * (double)up_h / dd - 1.0, 0.0);
+                score = mean + pen;
+                ok = (cnt > 8) && (score > 0.0);
+            }
+            const unsigned long long bal = __ballot(ok);
+            const int basec = s_ncand;
+            if (ok) {
+                const int pos = basec + __popcll(bal & ((1ull << tid) - 1ull));
+                cs[pos] = score;
+                ci[pos] = (unsigned short)(pr / nd);
+                cj[pos] = (unsigned short)(pr % nd);
+            }
+            if (tid == 0) s_ncand = basec + __popcll(bal);
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    // greedy matching = walk the candidates in stable descending score order and take every pair whose two peaks are both
+    // free (paf_to_pose.py:246-262): equivalently, repeatedly take the best (score desc, insertion order asc) candidate
+    // among those whose peaks are both still free
+    const int nc = s_ncand, maxc = min(ns, nd);
+    int n = 0;
+    while (n < maxc) {
+        double bs = -INFINITY;
+        int bk = 0x7fffffff;
+        for (int k = tid; k < nc; k += 256) {
+            const int i = ci[k], j = cj[k];
+            if (((s_used_i[i >> 5] >> (i & 31)) & 1u) || ((s_used_j[j >> 5] >> (j & 31)) & 1u)) continue;
+            const double sk = cs[k];
+            if (sk > bs || (sk == bs && k < bk) || bk == 0x7fffffff) { bs = sk; bk = k; }
+        }
+        s_best_s[tid] = bs;
+        s_best_k[tid] = bk;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                const double os = s_best_s[tid + off];
+                const int ok_ = s_best_k[tid + off];
+                const double ms = s_best_s[tid];
+                const int mk = s_best_k[tid];
+                if (ok_ != 0x7fffffff && (mk == 0x7fffffff || os > ms || (os == ms && ok_ < mk))) { s_best_s[tid] = os; s_best_k[tid] = ok_; }
+            }
+            __syncthreads();
+        }
+        const int k = s_best_k[0];
+        if (k == 0x7fffffff) break;                       // no free candidate left (block-uniform)
+        if (tid == 0) {
+            const int i = ci[k], j = cj[k];
+            s_used_i[i >> 5] |= 1u << (i & 31);
+            s_used_j[j >> 5] |= 1u << (j & 31);
+            W.conn_i[(size_t)limb * hw + n] = i;
+            W.conn_j[(size_t)limb * hw + n] = j;
+            W.conn_s[(size_t)limb * hw + n] = s_best_s[0];
+        }
+        ++n;
+        __syncthreads();
+    }
+    if (tid == 0) W.conn_count[limb] = n;
+}
+
+__global__ __launch_bounds__(256) void big_group_kernel(const float *__restrict__ heat, const float *__restrict__ z, int h, int w, pn_parse_cfg cfg, BigWs W) {
+    __shared__ int s_base[J_ + 1];
+    __shared__ int s_nh, s_h1, s_h2, s_overlap, s_np, s_nkeep;
+    const int tid = threadIdx.x;
+    const int hw = h * w;
+    constexpr int RW = J_ + 2;
+    if (tid == 0) {
+        int acc = 0;
+        for (int j = 0; j < J_; ++j) { s_base[j] = acc; acc += W.peak_count[j]; }
+        s_base[J_] = acc;
+        s_np = 0;
+    }
+    __syncthreads();
+    const int npeaks = s_base[J_];
+    for (int j = 0; j < J_; ++j) {
+        const int n = W.peak_count[j];
+        for (int k = tid; k < n; k += 256) {
+            const int id = s_base[j] + k;
+            W.o_peak[3 * (size_t)id + 0] = W.px[(size_t)j * hw + k];
+            W.o_peak[3 * (size_t)id + 1] = W.py[(size_t)j * hw + k];
+            W.o_peak[3 * (size_t)id + 2] = W.ps[(size_t)j * hw + k];
+            W.o_peak_type[id] = j;
+        }
+    }
+    double *rows = W.rows;
+    // ---- group_limbs_of_same_person (paf_to_pose.py:280-335): serial over connections, row search across the block ----
+    for (int limb = 0; limb < L_; ++limb) {
+        const int st = c_limb_src[limb], dt = c_limb_dst[limb];
+        const int nconn = W.conn_count[limb];
+        for (int cidx = 0; cidx < nconn; ++cidx) {
+            const int ci = W.conn_i[(size_t)limb * hw + cidx], cj = W.conn_j[(size_t)limb * hw + cidx];
+            const double src_id = (double)(s_base[st] + ci), dst_id = (double)(s_base[dt] + cj);
+            const double lscore = W.conn_s[(size_t)limb * hw + cidx];
+            const double s_src = (double)W.ps[(size_t)st * hw + ci], s_dst = (double)W.ps[(size_t)dt * hw + cj];
+            const int np = s_np;
+            if (tid == 0) { s_nh = 0; s_h1 = 0x7fffffff; s_h2 = 0x7fffffff; s_overlap = 0; }
+            __syncthreads();
+            for (int r = tid; r < np; r += 256)
+                if (rows[(size_t)r * RW + st] == src_id || rows[(size_t)r * RW + dt] == dst_id) { atomicAdd(&s_nh, 1); atomicMin(&s_h1, r); }
+            __syncthreads();
+            const int nh = s_nh, p1 = s_h1;
+            if (nh == 2) {
+                for (int r = tid; r < np; r += 256)
+                    if (r != p1 && (rows[(size_t)r * RW + st] == src_id || rows[(size_t)r * RW + dt] == dst_id)) atomicMin(&s_h2, r);
+                __syncthreads();
+                const int p2 = s_h2;
+                if (tid < J_ && rows[(size_t)p1 * RW + tid] >= 0.0 && rows[(size_t)p2 * RW + tid] >= 0.0) atomicOr(&s_overlap, 1);
+                __syncthreads();
+                if (!s_overlap) {
+                    if (tid < J_) rows[(size_t)p1 * RW + tid] += rows[(size_t)p2 * RW + tid] + 1.0;
+                    if (tid == 0) {
+                        rows[(size_t)p1 * RW + J_] += rows[(size_t)p2 * RW + J_];
+                        rows[(size_t)p1 * RW + J_ + 1] += rows[(size_t)p2 * RW + J_ + 1];
+                        rows[(size_t)p1 * RW + J_] += lscore;
+                    }
+                    __syncthreads();
+                    // person_to_joint_assoc.pop(p2): the later rows move down by one (through the second buffer)
+                    for (long long e = (long long)p2 * RW + tid; e < (long long)(np - 1) * RW; e += 256) W.rows2[e] = rows[e + RW];
+                    __threadfence_block();
+                    __syncthreads();
+                    for (long long e = (long long)p2 * RW + tid; e < (long long)(np - 1) * RW; e += 256) rows[e] = W.rows2[e];
+                    if (tid == 0) s_np = np - 1;
+                } else if (tid == 0) {
+                    rows[(size_t)p1 * RW + dt] = dst_id;
+                    rows[(size_t)p1 * RW + J_ + 1] += 1.0;
+                    rows[(size_t)p1 * RW + J_] += s_dst + lscore;
+                }
+            } else if (nh == 1) {
+                if (tid == 0 && rows[(size_t)p1 * RW + dt] != dst_id) {
+                    rows[(size_t)p1 * RW + dt] = dst_id;
+                    rows[(size_t)p1 * RW + J_ + 1] += 1.0;
+                    rows[(size_t)p1 * RW + J_] += s_dst + lscore;
+                }
+            } else {
+                if (tid < J_) rows[(size_t)np * RW + tid] = (tid == st) ? src_id : ((tid == dt) ? dst_id : -1.0);
+                if (tid == 0) {
+                    rows[(size_t)np * RW + J_ + 1] = 2.0;
+                    rows[(size_t)np * RW + J_] = (s_src + s_dst) + lscore;
+                    s_np = np + 1;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    // ---- prune (paf_to_pose.py:338-346), order kept ----
+    if (tid == 0) {
+        int nk = 0;
+        for (int r = 0; r < s_np; ++r) {
+            const double cnt = rows[(size_t)r * RW + J_ + 1], sc = rows[(size_t)r * RW + J_];
+            if (!(cnt < 3.0 || sc / cnt < 0.2)) W.keep_idx[nk++] = r;
+        }
+        s_nkeep = nk;
+        W.counts[0] = npeaks;
+        W.counts[1] = nk;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int nkeep = s_nkeep;
+    const double dsz = (double)cfg.downsample;
+    for (int t = tid; t < nkeep * J_; t += 256) {
+        const int o = t / J_, j = t - o * J_;
+        const int r = W.keep_idx[o];
+        const int id = (int)rows[(size_t)r * RW + j];
+        W.o_person_joint[(size_t)o * J_ + j] = id;
+        if (j == 0) {
+            W.o_person_score[o] = rows[(size_t)r * RW + J_];
+            W.o_person_count[o] = (int)rows[(size_t)r * RW + J_ + 1];
+        }
+        double x2 = -1.0, y2 = -1.0, depth = -1.0, conf = 0.0;
+        if (id >= 0) {
+            const int k = id - s_base[j];
+            const double x = (double)W.px[(size_t)j * hw + k], y = (double)W.py[(size_t)j * hw + k];
+            conf = (double)W.ps[(size_t)j * hw + k];
+            const int cx0 = (int)(x / dsz), cy0 = (int)(y / dsz);
+            const int min_x = min(max(cx0 - 1, 0), w - 1), max_x = max(min(cx0 + 1, w - 1), 0);
+            const int min_y = min(max(cy0 - 1, 0), h - 1), max_y = max(min(cy0 + 1, h - 1), 0);
+            const float *hm = heat + (size_t)j * hw;
+            const float *zm = z + (size_t)j * hw;
+            float pw_[9], ww_[9];
+            int n = 0;
+            for (int yy = min_y; yy <= max_y; ++yy)
+                for (int xx = min_x; xx <= max_x; ++xx) {
+                    float hv = hm[yy * w + xx];
+                    if (hv < 0.f) hv = 0.f;
+                    const float wv = hv + 0.000000001f;
+                    float dv = zm[yy * w + xx] * cfg.depth_std;
+                    dv = dv + cfg.depth_mean;
+                    pw_[n] = dv * wv;
+                    ww_[n] = wv;
+                    ++n;
+                }
+            float sp, sw;
+            if (n < 8) {
+                sp = -0.0f; sw = -0.0f;
+                for (int k2 = 0; k2 < n; ++k2) { sp = sp + pw_[k2]; sw = sw + ww_[k2]; }
+            } else {
+                sp = ((pw_[0] + pw_[1]) + (pw_[2] + pw_[3])) + ((pw_[4] + pw_[5]) + (pw_[6] + pw_[7]));
+                sw = ((ww_[0] + ww_[1]) + (ww_[2] + ww_[3])) + ((ww_[4] + ww_[5]) + (ww_[6] + ww_[7]));
+                for (int k2 = 8; k2 < n; ++k2) { sp = sp + pw_[k2]; sw = sw + ww_[k2]; }
+            }
+            depth = (double)(sp / sw);
+            x2 = x / (double)cfg.input_size * (double)cfg.w_org;
+            y2 = y / (double)cfg.input_size * (double)cfg.h_org;
+        }
+        const double X3 = (x2 - cfg.cx) * depth / cfg.fx, Y3 = (y2 - cfg.cy) * depth / cfg.fy;
+        W.o_j2d[2 * (size_t)t + 0] = x2;
+        W.o_j2d[2 * (size_t)t + 1] = y2;
+        W.o_j3d[3 * (size_t)t + 0] = X3;
+        W.o_j3d[3 * (size_t)t + 1] = Y3;
+        W.o_j3d[3 * (size_t)t + 2] = depth;
+        W.o_conf[t] = conf;
+    }
+}
+
+namespace {
+struct BigHost { BigWs w; size_t bytes_a = 0, bytes_b = 0; void *blk_a = nullptr, *blk_b = nullptr; int hw = 0, npeaks = 0, npersons = 0; };
+char *bump(char *&p, size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return r; }
+}  // namespace
+
+extern "C" int pn_parse_paf_unbounded(pn_ctx *ctx, const float *heat_dev, const float *paf_dev, const float *z_dev, int h, int w,
+                                      const pn_parse_cfg *cfg, int *n_peaks, int *n_persons, void *hip_stream) {
+    if (!ctx) return PN_ERR_INVALID;
+    if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
+    if (!heat_dev || !paf_dev || !z_dev || !cfg || !n_peaks || !n_persons) return pn_set_error(ctx, PN_ERR_INVALID, "pn_parse_paf_unbounded: bad arguments");
+    if (h * w > MAX_MAP || h < 1 || w < 1) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_paf_unbounded: map %dx%d exceeds %d cells", h, w, MAX_MAP);
+    if (cfg->downsample != 8 || cfg->num_intermed_pts != 10) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_parse_paf_unbounded: built for downsample=8, 10 intermediate points");
+    hipStream_t s = (hipStream_t)hip_stream;
+    BigHost *B = (BigHost *)ctx->parse_big;
+    if (!B) { B = new BigHost(); ctx->parse_big = B; }
+    const int hw = h * w;
+    // block A: everything whose size depends on the map only
+    {
+        const size_t need = 256 * 8 + (size_t)J_ * hw * 12 + (size_t)L_ * hw * 16 + 4096;
+        if (B->bytes_a < need) {
+            if (B->blk_a) { PN_HIP_CHECK(ctx, hipDeviceSynchronize()); (void)hipFree(B->blk_a); B->blk_a = nullptr; B->bytes_a = 0; }
+            PN_HIP_CHECK(ctx, hipMalloc(&B->blk_a, need));
+            B->bytes_a = need;
+        }
+        char *p = (char *)B->blk_a;
+        B->w.peak_count = (int *)bump(p, J_ * 4);
+        B->w.conn_count = (int *)bump(p, L_ * 4);
+        B->w.counts = (int *)bump(p, 2 * 4);
+        B->w.px = (float *)bump(p, (size_t)J_ * hw * 4);
+        B->w.py = (float *)bump(p, (size_t)J_ * hw * 4);
+        B->w.ps = (float *)bump(p, (size_t)J_ * hw * 4);
+        B->w.conn_i = (int *)bump(p, (size_t)L_ * hw * 4);
+        B->w.conn_j = (int *)bump(p, (size_t)L_ * hw * 4);
+        B->w.conn_s = (double *)bump(p, (size_t)L_ * hw * 8);
+    }
+    B->hw = hw;
+    CubicTab tab;
+    for (int p = 0; p < 8; ++p) host_cubic_coeffs((float)(2 * p + 1) / 16.0f, tab.c[p]);
+    hipLaunchKernelGGL(big_peaks_kernel, dim3(J_), dim3(256), 0, s, heat_dev, h, w, cfg->thresh_heatmap, tab, B->w);
+    int pc[J_];
+    PN_HIP_CHECK(ctx, hipMemcpyAsync(pc, B->w.peak_count, sizeof pc, hipMemcpyDeviceToHost, s));
+    PN_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    // block B: sized from this frame's peak counts
+    static const int lsrc[L_] = {8, 9, 11, 8, 10, 12, 8, 1, 2, 4, 1, 3, 5, 1}, ldst[L_] = {9, 11, 13, 10, 12, 14, 1, 2, 4, 6, 3, 5, 7, 0};
+    long long ncand = 0, maxp = 1, npk = 0;
+    for (int j = 0; j < J_; ++j) npk += pc[j];
+    for (int l = 0; l < L_; ++l) {
+        B->w.cand_off[l] = ncand;
+        ncand += (long long)pc[lsrc[l]] * pc[ldst[l]];
+        maxp += std::min(pc[lsrc[l]], pc[ldst[l]]);
+    }
+    B->w.cand_off[L_] = ncand;
+    B->w.maxp = (int)maxp;
+    {
+        const size_t need = (size_t)ncand * 12 + (size_t)maxp * ((J_ + 2) * 16 + 4 + J_ * 4 + 8 + 4 + J_ * (16 + 24 + 8)) + (size_t)npk * 16 + 16 * 256;
+        if (B->bytes_b < need) {
+            if (B->blk_b) { PN_HIP_CHECK(ctx, hipDeviceSynchronize()); (void)hipFree(B->blk_b); B->blk_b = nullptr; B->bytes_b = 0; }
+            PN_HIP_CHECK(ctx, hipMalloc(&B->blk_b, need + need / 4));
+            B->bytes_b = need + need / 4;
+        }
+        char *p = (char *)B->blk_b;
+        B->w.cand_s = (double *)bump(p, (size_t)ncand * 8);
+        B->w.cand_i = (unsigned short *)bump(p, (size_t)ncand * 2);
+        B->w.cand_j = (unsigned short *)bump(p, (size_t)ncand * 2);
+        B->w.rows = (double *)bump(p, (size_t)maxp * (J_ + 2) * 8);
+        B->w.rows2 = (double *)bump(p, (size_t)maxp * (J_ + 2) * 8);
+        B->w.keep_idx = (int *)bump(p, (size_t)maxp * 4);
+        B->w.o_peak = (float *)bump(p, (size_t)npk * 12);
+        B->w.o_peak_type = (int *)bump(p, (size_t)npk * 4);
+        B->w.o_person_joint = (int *)bump(p, (size_t)maxp * J_ * 4);
+        B->w.o_person_score = (double *)bump(p, (size_t)maxp * 8);
+        B->w.o_person_count = (int *)bump(p, (size_t)maxp * 4);
+        B->w.o_j2d = (double *)bump(p, (size_t)maxp * J_ * 16);
+        B->w.o_j3d = (double *)bump(p, (size_t)maxp * J_ * 24);
+        B->w.o_conf = (double *)bump(p, (size_t)maxp * J_ * 8);
+    }
+    hipLaunchKernelGGL(big_limb_kernel, dim3(L_), dim3(256), 0, s, paf_dev, h, w, cfg->thresh_paf, h * cfg->downsample, tab, B->w);
+    hipLaunchKernelGGL(big_group_kernel, dim3(1), dim3(256), 0, s, heat_dev, z_dev, h, w, *cfg, B->w);
+    int cnt[2] = {0, 0};
+    PN_HIP_CHECK(ctx, hipMemcpyAsync(cnt, B->w.counts, sizeof cnt, hipMemcpyDeviceToHost, s));
+    PN_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    B->npeaks = cnt[0];
+    B->npersons = cnt[1];
+    *n_peaks = cnt[0];
+    *n_persons = cnt[1];
+    return PN_OK;
+}
+
+extern "C" int pn_parse_paf_unbounded_fetch(pn_ctx *ctx, float *peaks_xys, int *peak_type, int *person_joint, double *person_score,
+                                            int *person_count, double *joints_2d, double *joints_3d, double *part_conf) {
+    if (!ctx) return PN_ERR_INVALID;
+    BigHost *B = (BigHost *)ctx->parse_big;
+    if (!B || !B->blk_b) return pn_set_error(ctx, PN_ERR_STATE, "pn_parse_paf_unbounded_fetch: no result (call pn_parse_paf_unbounded first)");
+    const size_t np = (size_t)B->npeaks, P = (size_t)B->npersons;
+    if (np && peaks_xys) PN_HIP_CHECK(ctx, hipMemcpy(peaks_xys, B->w.o_peak, np * 12, hipMemcpyDeviceToHost));
+    if (np && peak_type) PN_HIP_CHECK(ctx, hipMemcpy(peak_type, B->w.o_peak_type, np * 4, hipMemcpyDeviceToHost));
+    if (P && person_joint) PN_HIP_CHECK(ctx, hipMemcpy(person_joint, B->w.o_person_joint, P * J_ * 4, hipMemcpyDeviceToHost));
+    if (P && person_score) PN_HIP_CHECK(ctx, hipMemcpy(person_score, B->w.o_person_score, P * 8, hipMemcpyDeviceToHost));
+    if (P && person_count) PN_HIP_CHECK(ctx, hipMemcpy(person_count, B->w.o_person_count, P * 4, hipMemcpyDeviceToHost));
+    if (P && joints_2d) PN_HIP_CHECK(ctx, hipMemcpy(joints_2d, B->w.o_j2d, P * J_ * 16, hipMemcpyDeviceToHost));
+    if (P && joints_3d) PN_HIP_CHECK(ctx, hipMemcpy(joints_3d, B->w.o_j3d, P * J_ * 24, hipMemcpyDeviceToHost));
+    if (P && part_conf) PN_HIP_CHECK(ctx, hipMemcpy(part_conf, B->w.o_conf, P * J_ * 8, hipMemcpyDeviceToHost));
+    return PN_OK;
+}
+
+void pn_parse_big_free(pn_ctx *ctx) {
+    BigHost *B = (BigHost *)ctx->parse_big;
+    if (!B) return;
+    if (B->blk_a) (void)hipFree(B->blk_a);
+    if (B->blk_b) (void)hipFree(B->blk_b);
+    delete B;
+    ctx->parse_big = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------

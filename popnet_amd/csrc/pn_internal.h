@@ -14,6 +14,7 @@ struct pn_ctx {
     void *parse_ws = nullptr;
     size_t parse_ws_bytes = 0;
     bool parse_ws_fixed = false;     // pn_parse_reserve: the scratch never moves again
+    void *parse_big = nullptr;       // workspace of the unbounded second pass (parse_paf.hip::BigHost), freed by pn_parse_big_free
     // scratch of the training kernels (flipped weights, split-reduction partials; train.hip), stream-ordered reuse
     void *train_ws = nullptr;
     size_t train_ws_bytes = 0;
@@ -24,6 +25,7 @@ struct pn_ctx {
 };
 
 int pn_set_error(pn_ctx *ctx, int code, const char *fmt, ...);
+void pn_parse_big_free(pn_ctx *ctx);     // parse_paf.hip
 
 #define PN_HIP_CHECK(ctx, expr)                                                              \
     do {                                                                                     \

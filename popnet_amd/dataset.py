@@ -63,13 +63,23 @@ class MP3DHPFrames:
             yield chunk, np.stack(frames)
 
 
-def pose_records_to_lists(recs):
+def pose_records_to_lists(recs, overflow=None):
     """pn_pose_frame records -> the per-frame entries of human_pred_set_{2d,3d,visibility,part_conf} (float64 lists,
-    [-1, -1] / Z = -1 for joints a person does not have, exactly what the evaluation script appends)."""
+    [-1, -1] / Z = -1 for joints a person does not have, exactly what the evaluation script appends).
+    overflow: {frame index: result of utils.paf_to_pose.parse_paf_unbounded} for the frames whose record carries an overflow
+    status (PoseEngine.predict_lists fills it); without it such a frame raises -- it is never truncated silently."""
     out = {"human_pred_set_2d": [], "human_pred_set_3d": [], "human_pred_set_visibility": [], "human_pred_set_part_conf": []}
-    for fr in recs:
+    for i, fr in enumerate(recs):
         if int(fr["status"]):
-            raise _lib.PopnetError("pose record overflow (status=%d): raise PN_MAX_PEAKS_PER_JOINT / PN_MAX_PERSONS" % int(fr["status"]))
+            if overflow is None or i not in overflow:
+                raise _lib.PopnetError("pose record overflow (status=%d): more than %d peaks per joint map or %d persons -- re-parse the frame "
+                                       "with utils.paf_to_pose.parse_paf_unbounded / PoseEngine.predict_lists" % (int(fr["status"]), _lib.PN_MAX_PEAKS_PER_JOINT, _lib.PN_MAX_PERSONS))
+            r = overflow[i]
+            out["human_pred_set_2d"].append(r["joints_2d"].tolist())
+            out["human_pred_set_3d"].append(r["joints_3d"].tolist())
+            out["human_pred_set_visibility"].append((r["person_joint"] >= 0).astype(int).tolist())
+            out["human_pred_set_part_conf"].append(r["part_conf"].tolist())
+            continue
         n = int(fr["n_persons"])
         out["human_pred_set_2d"].append(np.asarray(fr["joints_2d"][:n], dtype=np.float64).tolist())
         out["human_pred_set_3d"].append(np.asarray(fr["joints_3d"][:n], dtype=np.float64).tolist())

@@ -125,6 +125,20 @@ class PoseEngine:
     def predict_host(self, depth):
         return records_to_numpy(self.predict(depth))
 
+    def predict_lists(self, depth):
+        """depth [B,H,W] -> the reference's per-frame result lists (dataset.pose_records_to_lists), with NO capacity limit:
+        a frame whose fixed-size record overflows (more than 32 peaks in a joint map or 32 persons) is parsed again from the
+        maps of this batch by the unbounded second pass (pn_parse_paf_unbounded), so it comes back as the reference would
+        return it instead of raising."""
+        return self.lists_from_records(records_to_numpy(self.predict(depth)))
+
+    def lists_from_records(self, recs):
+        """Result lists of the batch whose maps are in self.heat / self.paf / self.z and whose records are `recs` (numpy)."""
+        from .dataset import pose_records_to_lists
+        from .utils.paf_to_pose import parse_paf_unbounded
+        over = {i: parse_paf_unbounded(self.heat[i], self.paf[i], self.z[i], self.cfg) for i in range(len(recs)) if int(recs[i]["status"])}
+        return pose_records_to_lists(recs, over)
+
     def pack(self, frames, wire=None):
         """pn_pose_frame records (device, [B, sizeof]) -> compact pn_pose_wire records (device uint8 [B, sizeof], no sync):
         the form that is gathered across GPUs (6.2 KB instead of 33 KB per frame)."""

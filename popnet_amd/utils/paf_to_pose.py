@@ -80,6 +80,37 @@ def frame_assoc(fr):
     return out
 
 
+def parse_paf_unbounded(heat, paf, z, cfg):
+    """The parse WITHOUT the record capacities (pn_parse_paf_unbounded: the second pass for a frame the fixed-size record flags
+    as overflowing -- the reference itself has no limit, paf_to_pose.py:33-153,267-351).  heat [J+1,h,w], paf [2L,h,w],
+    z [L+1,h,w]: float32 CUDA tensors of ONE frame.  Returns a dict of variable-length arrays: joint_list [N,5] and
+    person_to_joint_assoc [P,J+2] as paf_to_pose returns them, plus joints_2d [P,J,2], joints_3d [P,J,3], part_conf [P,J]."""
+    for t, n in ((heat, "heat"), (paf, "paf"), (z, "z")):
+        _lib.require_cuda_tensor(t, n)
+    dev = heat.device
+    heat, paf, z = heat.contiguous().float(), paf.contiguous().float(), z.contiguous().float()
+    h, w = heat.shape[-2], heat.shape[-1]
+    ctx = _lib.Context.for_device(dev.index)
+    L = _lib.lib()
+    npk, npers = C.c_int(0), C.c_int(0)
+    ctx.check(L.pn_parse_paf_unbounded(ctx.handle, C.c_void_p(heat.data_ptr()), C.c_void_p(paf.data_ptr()), C.c_void_p(z.data_ptr()), h, w,
+                                       C.byref(cfg), C.byref(npk), C.byref(npers), _lib.current_stream_ptr(dev)), "pn_parse_paf_unbounded")
+    N, P, J = npk.value, npers.value, _lib.PN_NUM_JOINTS
+    xys, typ = np.zeros((N, 3), np.float32), np.zeros((N,), np.int32)
+    pj, psc, pcn = np.zeros((P, J), np.int32), np.zeros((P,), np.float64), np.zeros((P,), np.int32)
+    j2, j3, cf = np.zeros((P, J, 2), np.float64), np.zeros((P, J, 3), np.float64), np.zeros((P, J), np.float64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    ctx.check(L.pn_parse_paf_unbounded_fetch(ctx.handle, vp(xys), vp(typ), vp(pj), vp(psc), vp(pcn), vp(j2), vp(j3), vp(cf)), "pn_parse_paf_unbounded_fetch")
+    joint_list = np.empty((N, 5), np.float64)
+    joint_list[:, :3] = xys
+    joint_list[:, 3] = np.arange(N)
+    joint_list[:, 4] = typ
+    assoc = np.empty((P, J + 2), np.float64)
+    assoc[:, :J], assoc[:, J], assoc[:, J + 1] = pj, psc, pcn
+    return {"joint_list": joint_list if N else np.array([]), "person_to_joint_assoc": assoc if P else np.array([]),
+            "person_joint": pj, "joints_2d": j2, "joints_3d": j3, "part_conf": cf}
+
+
 def check_status(fr):
     if int(fr['status']):
         raise _lib.PopnetError("pose parse overflow (status=%d): more than %d peaks per joint or %d persons in a frame"
@@ -94,6 +125,10 @@ def paf_to_pose(heatmaps, pafs, config):
     hm = hm.to(dev, torch.float32).permute(2, 0, 1)[None].contiguous()
     pf = pf.to(dev, torch.float32).permute(2, 0, 1)[None].contiguous()
     z = torch.zeros((1, NUM_LIMBS + 1, hm.shape[2], hm.shape[3]), device=dev, dtype=torch.float32)
-    fr = parse_paf_batch(hm, pf, z, make_parse_cfg(config))[0]
-    check_status(fr)
+    cfg = make_parse_cfg(config)
+    fr = parse_paf_batch(hm, pf, z, cfg)[0]
+    if int(fr['status']):
+        # more peaks / persons than the fixed-size record holds: second pass without capacities (the reference has none)
+        r = parse_paf_unbounded(hm[0], pf[0], z[0], cfg)
+        return r["joint_list"], r["person_to_joint_assoc"]
     return frame_joint_list(fr), frame_assoc(fr)

@@ -309,15 +309,83 @@ def test_parse_full_batch_matches_oracle_and_is_batch_invariant(gpu):
             assert np.array_equal(fr["part_conf"][:n], np.array(rec["conf"]))
 
 
-def test_parse_overflow_is_flagged_not_silent(gpu):
-    """A constant heat map is one giant plateau: every cell is a peak.  The record must carry the
-    overflow status and the per-frame API must raise."""
+def _unbounded(gpu, heat_hwc, paf_hwc, z_hwc):
+    from popnet_amd.utils.paf_to_pose import make_parse_cfg, parse_paf_unbounded
+    t = [torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).to(gpu) for a in (heat_hwc, paf_hwc, z_hwc)]
+    return parse_paf_unbounded(t[0], t[1], t[2], make_parse_cfg(default_cfg()))
+
+
+def test_parse_overflow_second_pass_returns_the_reference_result(gpu):
+    """The reference has no capacity limit (paf_to_pose.py:33-153,267-351); the fixed-size record has (32 peaks per joint map,
+    32 persons).  A constant heat map is one giant plateau -- every one of the 784 cells of every joint map is a peak: the
+    record carries the overflow status (never a silent truncation) and the per-frame API answers through the unbounded second
+    pass (pn_parse_paf_unbounded) with the oracle's 15 x 784-row joint list."""
     from popnet_amd.utils.paf_to_pose import paf_to_pose
+    from oracle import parse_paf as oparse
     heat = np.full((28, 28, 16), 0.5, np.float32)
     fr = _parse(gpu, heat, np.zeros((28, 28, 28), np.float32), np.zeros((28, 28, 15), np.float32))
     assert int(fr["status"]) & _lib.PN_FRAME_OVERFLOW_PEAKS
+    jl, assoc = paf_to_pose(heat, np.zeros((28, 28, 28), np.float32), default_cfg())
+    ref = oparse.nms(heat)
+    want = np.concatenate([np.concatenate([pk, np.full((len(pk), 1), j)], axis=1) for j, pk in enumerate(ref)])
+    assert jl.shape == (15 * 784, 5) and np.array_equal(jl, want)
+    assert assoc.size == 0                                                   # no limb evidence in an all-zero PAF: no persons
+
+
+@pytest.mark.parametrize("name", all_parse_case_names())
+def test_unbounded_pass_equals_the_fixed_size_records_on_the_reference_goldens(gpu, golden, name):
+    """Same arithmetic, same order: on frames that fit the records the second pass must give what the fast path gives -- and
+    therefore what the reference gave (goldens)."""
+    heat, paf, z = parse_case_inputs(golden, name)
+    r = _unbounded(gpu, heat, paf, z)
+    g = golden.parse
+    assert np.array_equal(r["joint_list"].reshape(-1, 5), g["%s_joint_list" % name])
+    want = g["%s_assoc" % name]
+    got = r["person_to_joint_assoc"].reshape(-1, 17)
+    assert got.shape == want.shape
+    if want.size:
+        assert np.array_equal(got[:, :15], want[:, :15]) and np.array_equal(got[:, 16], want[:, 16])
+        assert np.allclose(got[:, 15], want[:, 15], rtol=1e-12, atol=0)
+    fr = _parse(gpu, heat, paf, z)
+    n = int(fr["n_persons"])
+    assert n == len(r["joints_2d"])
+    assert np.array_equal(fr["joints_2d"][:n], r["joints_2d"]) and np.array_equal(fr["joints_3d"][:n], r["joints_3d"])
+    assert np.array_equal(fr["part_conf"][:n], r["part_conf"]) and np.array_equal(fr["person_score"][:n], got[:, 15] if n else np.zeros(0))
+
+
+@pytest.mark.parametrize("persons,seed", [(40, 1), (48, 2)])
+def test_more_persons_than_the_record_holds_vs_oracle(gpu, persons, seed):
+    """40 / 48 planted persons in one frame: more than PN_MAX_PERSONS (and more than 32 peaks in every joint map).  The record
+    flags it; the second pass equals the oracle exactly -- joint list, person assignment, 2D / 3D joints, confidences -- and
+    PoseEngine.predict_lists hands such a frame back as result lists instead of raising."""
+    from popnet_amd import synth
+    from oracle import parse_paf as oparse
+    heat, paf, z = (a[0].transpose(1, 2, 0) for a in synth.planted_batch(700 + seed, [persons], noise=0.01))
+    fr = _parse(gpu, heat, paf, z)
+    assert int(fr["status"]) != 0
+    r = _unbounded(gpu, heat, paf, z)
+    ref = oparse.frame_to_records(heat.copy(), paf.copy(), z.copy())
+    assert np.array_equal(r["joint_list"], ref["joint_list"])
+    oa = np.asarray(ref["assoc"]).reshape(-1, 17)
+    got = r["person_to_joint_assoc"].reshape(-1, 17)
+    assert got.shape == oa.shape and got.shape[0] > 32
+    assert np.array_equal(got[:, :15], oa[:, :15]) and np.array_equal(got[:, 16], oa[:, 16]) and np.allclose(got[:, 15], oa[:, 15], rtol=1e-12, atol=0)
+    assert np.array_equal(r["joints_2d"], np.array(ref["humans_2d"])) and np.array_equal(r["joints_3d"], np.array(ref["humans_3d"]))
+    assert np.array_equal(r["part_conf"], np.array(ref["conf"]))
+    # engine level: a batch with one such frame among ordinary ones comes back as result lists, nothing raises or truncates
+    from popnet_amd.dataset import pose_records_to_lists
+    from popnet_amd.pipeline import PoseEngine, records_to_numpy
+    eng = PoseEngine(precision="fp32", device=gpu, max_batch=3)
+    hb, pb, zb = synth.planted_batch(700 + seed, [persons, 2, 3], noise=0.01)
+    eng.heat.copy_(torch.from_numpy(hb).to(gpu)); eng.paf.copy_(torch.from_numpy(pb).to(gpu)); eng.z.copy_(torch.from_numpy(zb).to(gpu))
+    eng.parse(3)
+    recs = records_to_numpy(eng.frames[:3])
+    assert int(recs[0]["status"]) != 0 and int(recs[1]["status"]) == 0
     with pytest.raises(_lib.PopnetError, match="overflow"):
-        paf_to_pose(heat, np.zeros((28, 28, 28), np.float32), default_cfg())
+        pose_records_to_lists(recs)
+    lists = eng.lists_from_records(recs)
+    assert np.array_equal(np.array(lists["human_pred_set_3d"][0]), np.array(ref["humans_3d"])) and len(lists["human_pred_set_2d"][0]) == got.shape[0]
+    assert len(lists["human_pred_set_2d"][1]) == int(recs[1]["n_persons"]) > 0
 
 
 # ---------------------------------------------------------------------------------------------
