@@ -570,29 +570,47 @@ def main():
     gc.collect()
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.net == "rtpose" and not args.no_extras and args.precision == "bf16":
-        # the tolerance-meeting fast mode through the SAME region code, then the secondary network
-        pm = pipelined_leg(args, dev, world, rank, dist, "rtpose", "bf16x3", want_h2d=not args.no_h2d, dist_active=False)["out"]
+        # the tolerance-meeting fast mode through the SAME region code, then the secondary network: each
+        # as a fresh CHILD process (started, not exec'ed; this process keeps its GPU context and idles) -- in-process a third
+        # StreamingEngine's streams share hardware queues with the first one's and its batches stop overlapping
+        # (YoloPoseNet: 54 k frames/s as the third in-process leg, 94 k on its own)
+        def child_leg(extra):
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--reps", str(args.reps),
+                   "--pipeline", str(args.pipeline), "--pool", str(args.pool), "--no-extras", "--no-cpu-baseline"] + extra
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": "child leg failed (rc %d): %s" % (r.returncode, r.stderr[-400:])}
+            return json.loads(lines[-1])
+        pm = child_leg(["--precision", "bf16x3"] + (["--no-h2d"] if args.no_h2d else []))
         x3 = out["precision_modes"]["bf16x3"]
-        rf = pm["roofline"]
-        out["parity_mode"] = {
-            "dtype": "bf16x3", "value": pm["value"], "unit": "frames/s", "ms_per_step": pm["ms_per_step"], "value_stat": pm["value_stat"],
-            "h2d_inclusive": pm.get("h2d_inclusive"),
-            "roofline": {"bound": "mfma", "kernel": rf["kernel"], "achieved": round(3 * rf["achieved"], 2), "peak": rf["peak"], "unit": "TFLOP/s",
-                         "frac": round(3 * rf["achieved"] / rf["peak"], 4), "algorithmic_tflops": rf["achieved"], "avg_launch_us": rf["avg_launch_us"],
-                         "what": "physical bf16 MFMA FLOPs = 3 x algorithmic (x_hi W_hi + x_lo W_hi + x_hi W_lo)",
-                         "conv_stack_algorithmic_tflops": rf["conv_stack"]["achieved"], "conv_stack_physical_frac": round(3 * rf["conv_stack"]["frac"], 4)},
-            "fidelity": {"threshold_calibrated_weights": x3["vs_fp32_threshold_calibrated_weights"], "separated_weights": x3["vs_fp32_separated_weights"]},
-            "what": "the same pipelined timed region (hipGraph replay, %d batches in flight, median of %d) with precision='bf16x3': every tensor as three bf16 planes, fp32-class results" % (args.pipeline, args.reps)}
-        gc.collect()
-        torch.cuda.empty_cache()
-        yl = pipelined_leg(args, dev, world, rank, dist, "yolo", "bf16", want_h2d=False, dist_active=False)["out"]
-        out["yolo"] = {"value": yl["value"], "unit": "frames/s", "ms_per_step": yl["ms_per_step"], "value_stat": yl["value_stat"], "dtype": "bf16",
-                       "roofline": {k: yl["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step")},
-                       "conv_stack": {k: yl["roofline"]["conv_stack"][k] for k in ("achieved", "frac", "launches_per_step", "ms_per_step", "by_kernel")},
-                       "frame_stats": yl["frame_stats"],
-                       "what": "YoloPoseNet forward + box decode / NMS / skeleton read-out (SURVEY 8a rows 7, 12) through the same pipelined region"}
-        gc.collect()
-        torch.cuda.empty_cache()
+        if "error" in pm:
+            out["parity_mode"] = pm
+        else:
+            rf = pm["roofline"]
+            out["parity_mode"] = {
+                "dtype": "bf16x3", "value": pm["value"], "unit": "frames/s", "ms_per_step": pm["ms_per_step"], "value_stat": pm["value_stat"],
+                "h2d_inclusive": pm.get("h2d_inclusive"),
+                "roofline": {"bound": "mfma", "kernel": rf["kernel"], "achieved": round(3 * rf["achieved"], 2), "peak": rf["peak"], "unit": "TFLOP/s",
+                             "frac": round(3 * rf["achieved"] / rf["peak"], 4), "algorithmic_tflops": rf["achieved"], "avg_launch_us": rf["avg_launch_us"],
+                             "what": "physical bf16 MFMA FLOPs = 3 x algorithmic (x_hi W_hi + x_lo W_hi + x_hi W_lo)",
+                             "conv_stack_algorithmic_tflops": rf["conv_stack"]["achieved"], "conv_stack_physical_frac": round(3 * rf["conv_stack"]["frac"], 4)},
+                "fidelity": {"threshold_calibrated_weights": x3["vs_fp32_threshold_calibrated_weights"], "separated_weights": x3["vs_fp32_separated_weights"]},
+                "what": "the same pipelined timed region (hipGraph replay, %d batches in flight, median of %d; its own process) with precision='bf16x3': every tensor as three bf16 planes, fp32-class results" % (args.pipeline, args.reps)}
+        yl = child_leg(["--net", "yolo", "--no-h2d"])
+        if "error" in yl:
+            out["yolo"] = yl
+        else:
+            out["yolo"] = {"value": yl["value"], "unit": "frames/s", "ms_per_step": yl["ms_per_step"], "value_stat": yl["value_stat"], "dtype": "bf16",
+                           "roofline": {k: yl["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step")},
+                           "conv_stack": {k: yl["roofline"]["conv_stack"][k] for k in ("achieved", "frac", "launches_per_step", "ms_per_step", "by_kernel")},
+                           "frame_stats": yl["frame_stats"],
+                           "what": "YoloPoseNet forward + box decode / NMS / skeleton read-out (SURVEY 8a rows 7, 12) through the same pipelined region (its own process)"}
+        # RCCL on this box: one fresh rank under torch.distributed.run with the process group initialised on
+        # backend "nccl" at world_size 1: the region's all-gather plus gather_records / the 22 MB gradient all-reduce on device tensors
+        rc = child_leg(["--force-dist", "--no-h2d", "--steps", "10", "--warmup", "3", "--reps", "1", "--pool", "2"])
+        out["rccl_check"] = rc if "error" in rc else dict(rc.get("dist", {"error": "no dist block in the child's line"}), value_with_process_group=rc["value"])
         out["train_step"] = train_step_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out))

@@ -178,11 +178,19 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                 const int sstep = chunk * (2 * KK) + ph;
                 const int anext = RING == 3 ? aaddr + ((ph + 1) % 3) * PN4_ASLOT : aaddr + (int)__builtin_amdgcn_readfirstlane(((sstep + 1) & 3) * PN4_ASLOT);
                 // (1) staging for later steps: one halo piece of the NEXT half (taps 0..5), the weight fragments of step s + 3
+                // (-DPN4_DMA_MID: issued between the 3rd and the 4th pixel tile's MFMAs instead of in front of the step's first MFMA)
+                auto stage = [&]() {
 #ifndef PN4_FAKE_NODMA_B                        // -DPN4_FAKE_*: timing-only ablations (wrong results), scripts/conv4lab.hip
-                if (tap < 6) dma_b(tap, (half + 1) & 1, hh + 1);
+                    if (tap < 6) dma_b(tap, (half + 1) & 1, hh + 1);
 #endif
 #ifndef PN4_FAKE_NODMA_A
-                dma_a(RING == 3 ? ph % 3 : (int)__builtin_amdgcn_readfirstlane((sstep + 3) & 3));
+                    dma_a(RING == 3 ? ph % 3 : (int)__builtin_amdgcn_readfirstlane((sstep + 3) & 3));
+#endif
+                };
+#ifndef PN4_DMA_MID
+                stage();
+#else
+                if (!MATH) stage();
 #endif
                 // (2) this step's 28 MFMAs; fragment reads for the next step / the next items between them
                 if (MATH) {
@@ -190,6 +198,9 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
 #pragma clang loop unroll(full)
                     for (int pt = 0; pt < PT; ++pt) {
                         const int j = ph * PT + pt, jr = j + BQ - 1;
+#ifdef PN4_DMA_MID
+                        if (pt == 3) { __builtin_amdgcn_sched_barrier(0); stage(); __builtin_amdgcn_sched_barrier(0); }
+#endif
 #ifndef PN4_FAKE_NOLDS
                         if (pt < CT)
                             aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + anext + pt * 1024);
