@@ -318,6 +318,11 @@ static int bb64_launch(pn_ctx *ctx, const BBProblem &P, int num_cus, hipStream_t
         PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bb64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS));
         configured = true;
     }
+    // experiment switch: POPNET_BB64_CUS = workgroups of the persistent launch (default: one per CU).  Fewer leave whole CUs to the
+    // kernels of other streams while this one runs (a bb64 workgroup owns its CU's LDS).
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("POPNET_BB64_CUS"); cap = e ? atoi(e) : 0; }
+    if (cap > 0 && cap < num_cus) num_cus = cap;
     const int grid = P.ntiles < num_cus ? P.ntiles : num_cus;
     hipLaunchKernelGGL(bb64_kernel, dim3(grid), dim3(512), BB_LDS, stream, P);
     PN_HIP_CHECK(ctx, hipGetLastError());

@@ -818,6 +818,15 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
             }
             PN_HIP_CHECK(ctx, hipEventRecord(pr->a, stream));
         }
+        // timing-only ablation (wrong results): POPNET_ABLATE_SKIP = comma-separated classes of launches to skip --
+        // "pool", "head" (<= 32-cout generic launches), "c1x1" (conv3 1x1), "c3" (conv3 3x3), "stem"; what would the pipelined
+        // throughput be if these launches cost nothing?  (scripts/experiments/tail_ablation.sh)
+        static const char *skip = getenv("POPNET_ABLATE_SKIP");
+        if (skip) {
+            const char *cls = st.type == Step::POOL ? "pool" : st.type == Step::STEM ? "stem" : st.type == Step::BBLOCK ? "bb64" :
+                              (st.launch.kern == 4 ? "conv4" : st.launch.kern == 3 ? (st.launch.ks == 1 ? "c1x1" : "c3") : "head");
+            if (strstr(skip, cls)) { if (pr) PN_HIP_CHECK(ctx, hipEventRecord(pr->b, stream)); continue; }
+        }
         if (st.type == Step::STEM) {
             const Buf &ob = n->bufs[st.out_buf];
             rc = pn_launch_stem(ctx, n->x3 ? PN_PREC_BF16X3 : n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, n->x3 ? ob.plane : 0, stream);
