@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpopnet_hip.so")
+LIB_PATH = os.environ.get("POPNET_LIB_PATH") or os.path.join(_HERE, "libpopnet_hip.so")      # the override is for kernel experiments (variant builds)
 
 PN_OK = 0
 PN_PREC_F32, PN_PREC_BF16, PN_PREC_BF16X3 = 0, 1, 2

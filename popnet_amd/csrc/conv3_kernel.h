@@ -62,7 +62,12 @@ __device__ __forceinline__ void pn_glds16_s(const void *sbase, unsigned voff, un
 // on large maps, whose 224-pixel tiles otherwise stream their whole weight slice twice).
 // RPG = output rows per wave group kept in the halo image: 4 for 24..30-column strips (4 x 28 = 112 pixels), 8 for
 // narrow maps (8 x 14 = 112: the 14x14 layers of YoloPoseNet), 8 as well for PT = 14.
-template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7>
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // native vector: storable through address-space pointers
+
+// TAIL: the instantiation whose blocks run a second 1x1 convolution on their 128-channel output tile instead of storing it
+// (ConvProblem::tail_w; its own instantiation so that the plain kernel's register allocation is untouched: with both epilogues
+// in one body the 128-register 1x1 kernel spilled 41 VGPRs)
+template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7, bool TAIL = false>
 __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CONV3_OCC)) void conv3_kernel(const ConvProblem *__restrict__ probs) {
     typedef __bf16 T;
     typedef Elem<PN_PREC_BF16>::Frag Frag;
@@ -298,6 +303,118 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
         PN_STAMP_AT(4 + 2 * (chunk & 3));
     }
 
+    // ---- fused 1x1 tail (ConvProblem::tail_w, net.hip::fuse_1x1_tails): this block's 128-channel tile is the whole input of
+    // a second 1x1 convolution (128 -> <= 32 channels, rtpose_light3d.py:266-267).  A lane's 8 finished values of a pixel tile
+    // (bias + activation + bf16, exactly what the epilogue below would store) are channels 32 wc + 8 q .. + 7 of pixel c: the B
+    // fragment of the second convolution's k-step wc.  The four waves park their fragments in LDS, then each wave runs the
+    // chained MFMAs of its pixel tiles over k-steps 0..3 -- the same accumulation chain as the two-launch path, bit for bit.
+    if constexpr (TAIL) {
+        static_assert(KS == 1 && WC == 4 && WP == 1 && PT == 7, "the fused tail is built for the 128-cout 1x1 block");
+        {
+            constexpr int LC = CT * 4;
+            const int cw = wc * (CT * 16) + LC * q;
+            float bias[LC];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const f32x4 b4 = *reinterpret_cast<const PN_GLOBAL f32x4 *>((const PN_GLOBAL float *)P.bias + cw + 4 * ct);
+                bias[4 * ct + 0] = b4[0]; bias[4 * ct + 1] = b4[1]; bias[4 * ct + 2] = b4[2]; bias[4 * ct + 3] = b4[3];
+            }
+            const int act = P.act;
+            __syncthreads();                             // every wave is done reading the halo image: its space becomes the fragment image
+            // (compile-time activation, as in the epilogues below: the run-time pn_activate switch, unrolled over 56 values, made this
+            // instantiation 100 KB of code -- more than the instruction cache -- and the launch 10 us slower)
+            auto park = [&](auto actc) {
+                constexpr int ACT = decltype(actc)::value;
+#pragma clang loop unroll(full)
+                for (int pt = 0; pt < PT; ++pt) {
+                    T ov[LC];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = acc[ct][pt][i] + bias[4 * ct + i];
+                            if (ACT == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
+                            else if (ACT == PN_ACT_LEAKY) v = v > 0.f ? v : v * 0.1f;
+                            ov[4 * ct + i] = (T)v;
+                        }
+                    *reinterpret_cast<u32x4 *>(smem + ((wc * PT + pt) * 64 + lane) * 16) = *reinterpret_cast<u32x4 *>(ov);
+                }
+            };
+            if (act == PN_ACT_RELU) park(std::integral_constant<int, PN_ACT_RELU>{});
+            else if (act == PN_ACT_LEAKY) park(std::integral_constant<int, PN_ACT_LEAKY>{});
+            else park(std::integral_constant<int, PN_ACT_NONE>{});           // net.hip::fuse_1x1_tails admits these three only
+            __syncthreads();
+#ifdef PN_TAIL_FAKE_NOMMA
+            return;
+#endif
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(P.tail_w), 0, 2 * 4 * 1024, 0x00020000);
+            unsigned tlane = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(tlane));              // keep the eight fragment loads BEHIND the barrier: hoisted above it they are live beside the 56 accumulators
+            Frag a2[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    a2[t][ks] = __builtin_bit_cast(Frag, __builtin_amdgcn_raw_buffer_load_b128(trs, tlane, (unsigned)((t * 4 + ks) * 1024), 0));
+            const int tcout = P.tail_cout, tact = P.tail_act;
+            const PN_GLOBAL float *tb = (const PN_GLOBAL float *)P.tail_bias;
+            PN_GLOBAL T *tout = P.tail_out ? (PN_GLOBAL T *)P.tail_out + P.tail_out_coff : nullptr;
+            PN_GLOBAL float *tnchw = (PN_GLOBAL float *)P.tail_nchw;
+            const int Ho = P.Ho;
+            const size_t hw = (size_t)Ho * Wo;
+            for (int pt = wave; pt < PT; pt += 4) {      // wave-uniform trip count
+                f32x4 c2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const Frag bf = read_b_frag<PN_PREC_BF16>(smem, ((ks * PT + pt) * 64 + lane) * 16);
+                    c2[0] = mma(a2[0][ks], bf, c2[0]);
+                    c2[1] = mma(a2[1][ks], bf, c2[1]);
+                }
+                const int slot = pt * 16 + c;
+                if (slot < npix) {
+                    const int ry = (int)(((float)slot + 0.5f) * inv_wc), rx = slot - ry * Wc;
+                    const size_t opix = (size_t)(b * Ho + oy0 + ry) * Wo + ox0 + rx;
+                    // a lane holds channels 8q .. 8q + 7 of its pixel: one 16-byte NHWC store (8 bytes when only the first four
+                    // exist: 28 PAF channels); element-wise 2-byte stores into 384-byte pixel lines cost more than the whole tail
+                    float v8[8];
+                    T o8[8];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int ch = 8 * q + 4 * t + i;
+                            float v = c2[t][i] + tb[ch < tcout ? ch : 0];
+#ifndef PN_TAIL_FAKE_NOACT
+                            // the two sigmoid casts of the heads (rtpose_light3d.py:335-337) or none: same expressions as pn_activate
+                            if (tact == PN_ACT_SIG_PM2) v = (pn_sigmoid(v) - 0.5f) * 4.f;
+                            else if (tact == PN_ACT_SIG) v = pn_sigmoid(v);
+#endif
+                            v8[4 * t + i] = ch < tcout ? v : 0.f;
+                            o8[4 * t + i] = (T)v8[4 * t + i];
+                        }
+                    const int nvalid = tcout - 8 * q;
+#ifndef PN_TAIL_FAKE_NOSTORE
+                    if (tout && nvalid > 0) {
+                        PN_GLOBAL T *op = tout + opix * (size_t)P.tail_out_cs + 8 * q;
+                        if (nvalid >= 8) *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(o8);
+                        else if (nvalid == 4) *reinterpret_cast<PN_GLOBAL u32x2 *>(op) = *reinterpret_cast<u32x2 *>(o8);
+                        else
+                            for (int k = 0; k < nvalid; ++k) op[k] = o8[k];
+                    }
+                    if (tnchw)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (8 * q + k < tcout) tnchw[((size_t)b * tcout + 8 * q + k) * hw + (size_t)(oy0 + ry) * Wo + (ox0 + rx)] = v8[k];
+#else
+                    if (v8[0] == 123.456f && nvalid > 0 && tnchw) tnchw[0] = v8[1] + v8[2] + v8[3] + v8[4] + v8[5] + v8[6] + v8[7];
+#endif
+                }
+            }
+            PN_STAMP_AT(12);
+            return;
+        }
+    }
+
     // ---- epilogue: identical contract to conv_mfma_kernel.h (permuted cout rows, direct stores) ----
     PN_STAMP_AT(11);
     constexpr int LC = CT * 4;
@@ -453,9 +570,9 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     PN_STAMP_AT(12);
 }
 
-template <int KS, int WC, int WP, int NBUF, int PT = 7, int RPG = PT * 4 / 7>
+template <int KS, int WC, int WP, int NBUF, int PT = 7, int RPG = PT * 4 / 7, bool TAIL = false>
 static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
-    auto kern = conv3_kernel<KS, WC, WP, NBUF, PT, RPG>;
+    auto kern = conv3_kernel<KS, WC, WP, NBUF, PT, RPG, TAIL>;
     if (L.lds_bytes > 48 * 1024) {
         static size_t configured = 0;   // per instantiation
         if (configured < L.lds_bytes) {
@@ -469,7 +586,9 @@ static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream
     return PN_OK;
 }
 #define PN3_CASE(KS, WC, WP, NB) \
-    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && !L.tail) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
+#define PN3_CASE_TAIL(KS, WC, WP, NB) \
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && L.tail) return conv3_launch_one<KS, WC, WP, NB, 7, 4, true>(ctx, L, stream);
 #define PN3_CASE_PT(KS, WC, WP, NB, PT_) \
     if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == PT_ && L.rpg == PT_ * 4 / 7) return conv3_launch_one<KS, WC, WP, NB, PT_>(ctx, L, stream);
 #define PN3_CASE_RPG(KS, WC, WP, NB, RPG_) \

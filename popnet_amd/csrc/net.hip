@@ -54,6 +54,10 @@ struct ConvSpec {
     void *wpack = nullptr;
     float *bias = nullptr;
     double flops = 0;
+    int tail_conv = -1;       // fuse_1x1_tails: index of the 1x1 conv (<= 32 couts) that runs inside this conv's launch on its output tile
+    bool fused_away = false;  // this conv runs as the tail of another one: it has no launch of its own
+    void *tail_wpack = nullptr;
+    float *tail_bias = nullptr;
 };
 
 struct Step {
@@ -431,7 +435,7 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         const ConvSpec &a = n->convs[ids[i]];
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
-            if (!used[j] && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
+            if (!used[j] && (b.tail_conv >= 0) == (a.tail_conv >= 0) && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
                 (a.kern == 4 || (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg))) {
                 st.conv_ids.push_back(ids[j]);
                 used[j] = true;
@@ -575,6 +579,81 @@ int add_bblock(pn_net *n, int ia, int ib) {
     return PN_OK;
 }
 
+// The PAF branch ends in `1x1 256 -> 128 + BN + LeakyReLU` followed by `1x1 128 -> 28 + bias` (rtpose_light3d.py:266-267): per pixel
+// independent, so the second convolution can run on the first one's output tile before it ever leaves the CU.  A conv A
+// (1x1, exactly 128 couts = one conv3 block of 4 waves) whose output buffer is read by exactly one conv B (1x1, 128 -> <= 32
+// channels, next level) takes B as its tail: B disappears from its level, A's launch writes B's output.  bf16 only (the
+// three-plane bf16x3 form keeps the two-launch path); POPNET_NO_TAILFUSE=1 keeps the two launches (bit-identity tests).
+void fuse_1x1_tails(pn_net *n, std::vector<std::vector<int>> &levels) {
+    if (n->prec != PN_PREC_BF16 || n->x3 || getenv("POPNET_NO_TAILFUSE") || getenv("POPNET_NO_CONV3")) return;
+    for (size_t li = 0; li + 1 < levels.size(); ++li) {
+        if (levels[li].empty() || levels[li][0] < 0 || levels[li + 1].empty() || levels[li + 1][0] < 0) continue;
+        for (int ia : levels[li]) {
+            ConvSpec &a = n->convs[ia];
+            if (a.kern != 3 || a.ks != 1 || a.stride != 1 || a.cout != 128 || a.wc != 4 || a.wp != 1 || a.res_buf >= 0 || a.nchw_slot >= 0 || a.out_buf < 0 || a.out_coff != 0 ||
+                (a.act != PN_ACT_NONE && a.act != PN_ACT_RELU && a.act != PN_ACT_LEAKY))
+                continue;
+            // the only reader of A's output before the buffer is written again must be ONE conv of the next level
+            int readers = 0, ib = -1;
+            bool rewritten = false, other_reader = false;
+            for (size_t lj = li + 1; lj < levels.size() && !rewritten; ++lj) {
+                if (levels[lj].empty()) continue;
+                if (levels[lj][0] == -1) {                               // pool marker {-1, mode, in, out, C, coff}
+                    if (levels[lj][2] == a.out_buf) other_reader = true;
+                    if (levels[lj][3] == a.out_buf) rewritten = true;
+                    continue;
+                }
+                for (size_t k = levels[lj][0] == -2 ? 1 : 0; k < levels[lj].size(); ++k) {
+                    const ConvSpec &c = n->convs[levels[lj][k]];
+                    if (c.in_buf == a.out_buf || c.res_buf == a.out_buf) {
+                        if (lj == li + 1 && levels[lj][0] >= 0) { ++readers; ib = levels[lj][k]; }
+                        else other_reader = true;
+                    }
+                }
+                for (size_t k = levels[lj][0] == -2 ? 1 : 0; k < levels[lj].size(); ++k)
+                    if (n->convs[levels[lj][k]].out_buf == a.out_buf) rewritten = true;
+            }
+            if (readers != 1 || other_reader) continue;
+            ConvSpec &b = n->convs[ib];
+            if (std::find(levels[li + 1].begin(), levels[li + 1].end(), ib) == levels[li + 1].end()) continue;
+            const HostTensor *wb = find_t(n, b.w + ".weight");
+            if (!wb || wb->shape.size() != 4 || b.ks != 1 || b.stride != 1 || wb->shape[1] != 128 || wb->shape[0] > 32 || !b.bn.empty() || b.res_buf >= 0 || b.in_coff != 0 ||
+                (b.act != PN_ACT_NONE && b.act != PN_ACT_SIG && b.act != PN_ACT_SIG_PM2) ||
+                !b.cin_map.empty())
+                continue;
+            a.tail_conv = ib;
+            b.fused_away = true;
+            a.flops += b.flops;
+            levels[li + 1].erase(std::find(levels[li + 1].begin(), levels[li + 1].end(), ib));
+        }
+    }
+    levels.erase(std::remove_if(levels.begin(), levels.end(), [](const std::vector<int> &l) { return l.empty(); }), levels.end());
+}
+
+int pack_tail(pn_net *n, ConvSpec &a) {
+    pn_ctx *ctx = n->ctx;
+    const ConvSpec &b = n->convs[a.tail_conv];
+    const HostTensor *w = find_t(n, b.w + ".weight"), *bias = find_t(n, b.w + ".bias");
+    const int cout = (int)w->shape[0];
+    std::vector<uint16_t> pk((size_t)2 * 4 * 64 * 8, 0);
+    for (int t = 0; t < 2; ++t)
+        for (int ks = 0; ks < 4; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = pn_conv_row_channel(t, lane & 15, 2), q = lane >> 4;
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = ks * 32 + 8 * q + j;
+                    pk[(((size_t)t * 4 + ks) * 64 + lane) * 8 + j] = f32_to_bf16(co < cout ? w->data[(size_t)co * 128 + ci] : 0.f);
+                }
+            }
+    if (int rc = dev_alloc(n, &a.tail_wpack, pk.size() * 2, false)) return rc;
+    PN_HIP_CHECK(ctx, hipMemcpy(a.tail_wpack, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    std::vector<float> hb(32, 0.f);
+    for (int o = 0; o < cout; ++o) hb[o] = bias ? bias->data[o] : 0.f;
+    if (int rc = dev_alloc(n, (void **)&a.tail_bias, 32 * 4, false)) return rc;
+    PN_HIP_CHECK(ctx, hipMemcpy(a.tail_bias, hb.data(), 32 * 4, hipMemcpyHostToDevice));
+    return PN_OK;
+}
+
 // ---- graph builders -------------------------------------------------------------------------
 int build_rtpose(pn_net *n) {
     const int H = n->in_h, W = n->in_w;
@@ -652,6 +731,10 @@ int build_rtpose(pn_net *n) {
         if (int rc = prepare_conv(n, cs)) return rc;
     for (auto &cs : n->convs) n->flops_per_frame += cs.flops;
     fuse_basic_blocks(n, levels);
+    fuse_1x1_tails(n, levels);
+    for (auto &cs : n->convs)
+        if (cs.tail_conv >= 0)
+            if (int rc = pack_tail(n, cs)) return rc;
     for (auto &lv : levels) {
         if (lv[0] == -1) add_pool(n, lv[1], lv[2], lv[3], lv[4], lv[5]);
         else if (lv[0] == -2) { if (int rc = add_bblock(n, lv[1], lv[2])) return rc; }
@@ -723,7 +806,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         const int BC = c0.kern == 4 ? 128 : (c0.kern == 3 ? c0.wc * 32 : pn_cfg_couts(c0.cfg));
         st.host_probs.clear();
         int max_blocks = 0;
-        bool two_bufs = false;
+        bool two_bufs = false, has_tail = false;
         for (int id : st.conv_ids) {
             const ConvSpec &cs = n->convs[id];
             const Buf &ib = n->bufs[cs.in_buf];
@@ -756,6 +839,14 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
             P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
             P.in_zero_off = (unsigned)((size_t)n->max_batch * ib.H * ib.W * ib.C * es);      // zero page behind every activation buffer
+            if (cs.tail_conv >= 0) {
+                const ConvSpec &tb = n->convs[cs.tail_conv];
+                P.tail_w = cs.tail_wpack; P.tail_bias = cs.tail_bias; P.tail_cout = tb.cout; P.tail_act = tb.act;
+                if (tb.out_buf >= 0) { P.tail_out = n->bufs[tb.out_buf].p; P.tail_out_cs = n->bufs[tb.out_buf].C; P.tail_out_coff = tb.out_coff; }
+                if (tb.nchw_slot >= 0) P.tail_nchw = n->nchw_ptr[tb.nchw_slot];
+                P.out = nullptr;                       // the 128-channel tile never leaves the CU
+                has_tail = true;
+            }
             if (P.lds_two) two_bufs = true;
             max_blocks = std::max(max_blocks, P.nblocks);
             st.host_probs.push_back(P);
@@ -767,6 +858,8 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R) * (two_bufs ? 2 : 1);
         st.launch.kern = c0.kern; st.launch.wc = c0.wc; st.launch.wp = c0.wp; st.launch.nbuf = c0.nbuf; st.launch.pt = c0.pt; st.launch.rpg = c0.rpg;
         if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf, c0.rpg);
+        st.launch.tail = (c0.kern == 3 && has_tail) ? 1 : 0;
+        if (st.launch.tail) st.launch.lds_bytes = std::max<size_t>(st.launch.lds_bytes, 4 * 7 * 1024 + 1024);   // the tail's fragment image
         if (c0.kern == 4) st.launch.lds_bytes = 0;                        // conv4_launch knows its own size
         st.launch.probs_dev = st.dev_probs;
         PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),

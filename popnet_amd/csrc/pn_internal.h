@@ -80,6 +80,15 @@ struct ConvProblem {
     // three times the channels and the packed weights are [W_hi | W_hi | W_lo] (net.hip::prepare_conv).
     int split;             // plane distance (channels) of the OUTPUT tensor, 0 = not split
     int res_split;         // plane distance of the residual tensor (hi + lo are added), 0 = not split
+    // fused 1x1 tail (conv3_kernel<1, 4, 1, ...> only; net.hip::fuse_1x1_tails): when tail_w != nullptr the block's 128-channel
+    // output tile is NOT stored; a second 1x1 convolution (128 -> tail_cout <= 32 channels) runs on it from LDS and only ITS
+    // result leaves the kernel -- the `1x1 256 -> 128 + BN + LeakyReLU, then 1x1 128 -> 28` tail of the PAF branch
+    // (tpm/lib/network/rtpose_light3d.py:266-267) as one launch instead of two.
+    const void *tail_w;    // [2 cout tiles][4 k-steps][64 lanes][8 bf16], rows permuted with pn_conv_row_channel(tile, row, 2)
+    const float *tail_bias;
+    void *tail_out;        // NHWC (T) or nullptr
+    float *tail_nchw;      // NCHW f32 or nullptr
+    int tail_cout, tail_act, tail_out_cs, tail_out_coff;
 };
 
 // Tile configuration ids (see conv_mfma.hip).
@@ -109,6 +118,7 @@ struct ConvLaunch {
     int pitch;     // LDS halo row pitch in pixels (multiple of 8, >= halo columns)
     int cfg;       // pn_conv_cfg
     int kern = 0, wc = 0, wp = 0, nbuf = 0, pt = 7, rpg = 4;   // kern 3: conv3_kernel<ks, wc, wp, nbuf, pt, rpg>
+    int tail = 0;            // kern 3: every problem of the launch carries a fused 1x1 tail (ConvProblem::tail_w)
     int nprob;
     int max_blocks;          // max nblocks over the group
     size_t lds_bytes;
