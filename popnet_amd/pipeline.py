@@ -23,6 +23,10 @@ from .network.rtpose_light3d import rtpose_light3d
 from .utils.paf_to_pose import make_parse_cfg
 
 
+import os as _os
+_ABLATE_SKIP = _os.environ.get("POPNET_ABLATE_SKIP", "")
+
+
 class PoseEngine:
     def __init__(self, precision="bf16", state_dict=None, device=None, max_batch=32, input_size=224,
                  w_org=480, h_org=640, intrinsics=INTRINSICS, weight_seed=0, private_ctx=False, calib_gain=1.0):
@@ -110,6 +114,8 @@ class PoseEngine:
         """wire: optional device uint8 tensor [>= B, sizeof(pn_pose_wire)] that receives the compact records in the same launch."""
         frames = self.frames if frames is None else frames
         h = self.S // 8
+        if "parse" in _ABLATE_SKIP:              # timing-only ablation (scripts/experiments/tail_ablation.sh): wrong results
+            return
         self.ctx.check(self.L.pn_parse_paf_wire(self.ctx.handle, C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.paf.data_ptr()),
                                                 C.c_void_p(self.z.data_ptr()), B, h, h, C.byref(self.cfg), C.c_void_p(frames.data_ptr()),
                                                 C.c_void_p(wire.data_ptr() if wire is not None else None),
