@@ -54,6 +54,7 @@ struct ConvSpec {
     void *wpack = nullptr;
     float *bias = nullptr;
     double flops = 0;
+    bool embed_center = false; // a 1x1 convolution run as the centre tap of a 3x3 one (zero weights elsewhere), so that it shares the launch of a 3x3 sibling
     int tail_conv = -1;       // fuse_1x1_tails: index of the 1x1 conv (<= 32 couts) that runs inside this conv's launch on its output tile
     bool fused_away = false;  // this conv runs as the tail of another one: it has no launch of its own
     void *tail_wpack = nullptr;
@@ -168,9 +169,13 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const HostTensor *w = find_t(n, cs.w + ".weight");
     if (!w || w->shape.size() != 4)
         return pn_set_error(ctx, PN_ERR_INVALID, "missing conv weight %s.weight", cs.w.c_str());
-    const int cout = (int)w->shape[0], cin_ref = (int)w->shape[1], ks = (int)w->shape[2];
-    if (ks != cs.ks || (int)w->shape[3] != ks)
-        return pn_set_error(ctx, PN_ERR_INVALID, "%s.weight: kernel %dx%d, expected %d", cs.w.c_str(), ks, (int)w->shape[3], cs.ks);
+    const int cout = (int)w->shape[0], cin_ref = (int)w->shape[1], wks = (int)w->shape[2];
+    // embed_center: the 1x1 shortcut of a BasicBlock as the centre tap of a 3x3 "same" convolution -- eight taps of exact zeros
+    // leave every accumulator unchanged, the two non-zero k-steps come in the 1x1 kernel's order: bit-identical, one launch less
+    if (cs.embed_center && (n->prec == PN_PREC_F32 || getenv("POPNET_NO_EMBED1X1") || getenv("POPNET_NO_CONV3"))) { cs.embed_center = false; cs.ks = 1; }
+    const int ks = cs.embed_center ? 3 : wks;
+    if ((cs.embed_center ? wks != 1 : wks != cs.ks) || (int)w->shape[3] != wks)
+        return pn_set_error(ctx, PN_ERR_INVALID, "%s.weight: kernel %dx%d, expected %d", cs.w.c_str(), wks, (int)w->shape[3], cs.ks);
     cs.cout = cout;
     std::vector<int> map = cs.cin_map;
     if (map.empty()) {
@@ -241,7 +246,8 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     auto wval = [&](int co, int idx, int tap) -> float {      // folded weight of packed input channel idx
         const int ci = map[idx];
         if (co >= cout || ci < 0) return 0.f;
-        const float v = (float)((double)w->data[((size_t)co * cin_ref + ci) * (ks * ks) + tap] * scale[co]);
+        if (cs.embed_center && tap != 4) return 0.f;
+        const float v = (float)((double)w->data[((size_t)co * cin_ref + ci) * (wks * wks) + (cs.embed_center ? 0 : tap)] * scale[co]);
         if (!n->x3) return v;
         uint32_t hb = (uint32_t)f32_to_bf16(v) << 16;
         float hi;
@@ -334,7 +340,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
     if (cs.kern == 3 || cs.kern == 4) {
         cs.pitch = 32;
-        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
+        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * (cs.embed_center ? 1 : KK);       // algorithmic FLOPs: the embedded zeros do not count
         if (cs.out_buf >= 0) {
             const Buf &ob = n->bufs[cs.out_buf];
             if (ob.H != Ho || ob.W != Wo) return pn_set_error(ctx, PN_ERR_INVALID, "%s: output buffer is %dx%d, conv gives %dx%d", cs.w.c_str(), ob.H, ob.W, Ho, Wo);
@@ -688,7 +694,8 @@ int build_rtpose(pn_net *n) {
     levels.push_back({-1, 0, A1, P1, 64, 0});    // avgpool1 marker: {-1, mode, in, out, C, out_coff}
     // layer2: BasicBlock(64->128) with 1x1 shortcut @ H/4
     level({add_conv(n, "model0.layer2.0.conv1", "model0.layer2.0.bn1", 3, 1, P1, 0, T2, 0, PN_ACT_RELU),
-           add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", 1, 1, P1, 0, D2, 0, PN_ACT_NONE)});
+           add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", 3, 1, P1, 0, D2, 0, PN_ACT_NONE)});
+    n->convs.back().embed_center = true;       // the 1x1 shortcut rides in conv1's 3x3 launch (prepare_conv falls back to a 1x1 launch in fp32 mode)
     level({add_conv(n, "model0.layer2.0.conv2", "model0.layer2.0.bn2", 3, 1, T2, 0, A3, 0, PN_ACT_RELU, D2)});
     level({add_conv(n, "model0.conv2", "model0.bn2", 1, 1, A3, 0, A4, 0, PN_ACT_RELU)});
     levels.push_back({-1, 0, A4, CAT, 128, 0});  // avgpool2 -> feat slice of the concat buffer
