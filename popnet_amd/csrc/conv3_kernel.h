@@ -68,7 +68,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // native vect
 // (ConvProblem::tail_w; its own instantiation so that the plain kernel's register allocation is untouched: with both epilogues
 // in one body the 128-register 1x1 kernel spilled 41 VGPRs)
 template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7, bool TAIL = false>
-__global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CONV3_OCC)) void conv3_kernel(const ConvProblem *__restrict__ probs) {
+__device__ __forceinline__ void conv3_body(const ConvProblem &P) {
     typedef __bf16 T;
     typedef Elem<PN_PREC_BF16>::Frag Frag;
     constexpr int CT = 2, NW = WC * WP;
@@ -98,7 +98,6 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     constexpr int DB = PT == 14 ? PN_CONV3_DB14 : PN_CONV3_DB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const ConvProblem &P = probs[blockIdx.y];
     if ((int)blockIdx.x >= P.nblocks) return;
     int bx;
     {   // XCD-aware remap, see conv_mfma_kernel.h
@@ -570,6 +569,23 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     PN_STAMP_AT(12);
 }
 
+template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7, bool TAIL = false>
+__global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CONV3_OCC)) void conv3_kernel(const ConvProblem *__restrict__ probs) {
+    conv3_body<KS, WC, WP, NBUF, PT, RPG, TAIL>(probs[blockIdx.y]);
+}
+
+// One launch for the two kinds of 128-cout blocks a stage's fourth level holds (rtpose_light3d.py:263-309): the 3x3 convolutions of
+// the heat / depth branches and the fused 1x1 + 1x1 tail of the PAF branch.  Alone, neither fills the chip (448 and 224 blocks of
+// 4 waves for 1 024 SIMDs x 4 slots) and each pays its own ramp, drain and kernel boundary; a block picks its body by a scalar
+// test of its problem (same block shape, same 128-register budget; LDS = the larger of the two).  Same code per block as the
+// separate launches: results are bit-identical (POPNET_NO_MIX=1 keeps the two launches).
+template <int UNUSED = 0>      // a template only so that the header can hold it: instantiated in conv3_inst_0.hip alone
+__global__ __launch_bounds__(256, PN_CONV3_OCC) void conv3_mix_kernel(const ConvProblem *__restrict__ probs) {
+    const ConvProblem &P = probs[blockIdx.y];
+    if (P.tail_w) conv3_body<1, 4, 1, 1, 7, 4, true>(P);
+    else conv3_body<3, 4, 1, 1, 7, 4, false>(P);
+}
+
 template <int KS, int WC, int WP, int NBUF, int PT = 7, int RPG = PT * 4 / 7, bool TAIL = false>
 static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
     auto kern = conv3_kernel<KS, WC, WP, NBUF, PT, RPG, TAIL>;
@@ -586,7 +602,7 @@ static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream
     return PN_OK;
 }
 #define PN3_CASE(KS, WC, WP, NB) \
-    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && !L.tail) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
+    if (!L.mix && L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && !L.tail) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
 #define PN3_CASE_TAIL(KS, WC, WP, NB) \
     if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && L.tail) return conv3_launch_one<KS, WC, WP, NB, 7, 4, true>(ctx, L, stream);
 #define PN3_CASE_PT(KS, WC, WP, NB, PT_) \

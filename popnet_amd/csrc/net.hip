@@ -439,10 +439,18 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         Step st;
         st.type = Step::CONV;
         const ConvSpec &a = n->convs[ids[i]];
+        // conv3_mix_kernel: the 128-cout 3x3 blocks and the fused-tail 1x1 blocks of a level share one launch
+        static const bool no_mix = getenv("POPNET_NO_MIX") != nullptr;
+        auto mixable = [](const ConvSpec &c) {
+            return c.kern == 3 && c.stride == 1 && c.wc == 4 && c.wp == 1 && c.nbuf == 1 && c.pt == 7 && c.rpg == 4 && ((c.ks == 3 && c.tail_conv < 0) || (c.ks == 1 && c.tail_conv >= 0));
+        };
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
-            if (!used[j] && (b.tail_conv >= 0) == (a.tail_conv >= 0) && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
-                (a.kern == 4 || (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg))) {
+            if (used[j]) continue;
+            const bool same = (b.tail_conv >= 0) == (a.tail_conv >= 0) && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
+                (a.kern == 4 || (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg));
+            const bool mixed = !no_mix && mixable(a) && mixable(b) && b.R == a.R && b.Wt == a.Wt;
+            if (same || mixed) {
                 st.conv_ids.push_back(ids[j]);
                 used[j] = true;
             }
@@ -866,7 +874,15 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.kern = c0.kern; st.launch.wc = c0.wc; st.launch.wp = c0.wp; st.launch.nbuf = c0.nbuf; st.launch.pt = c0.pt; st.launch.rpg = c0.rpg;
         if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf, c0.rpg);
         st.launch.tail = (c0.kern == 3 && has_tail) ? 1 : 0;
-        if (st.launch.tail) st.launch.lds_bytes = std::max<size_t>(st.launch.lds_bytes, 4 * 7 * 1024 + 1024);   // the tail's fragment image
+        st.launch.mix = 0;
+        if (st.launch.tail) {
+            for (int id : st.conv_ids) {
+                const ConvSpec &cs = n->convs[id];
+                if (cs.tail_conv < 0) st.launch.mix = 1;                                               // 3x3 siblings in the launch: conv3_mix_kernel
+                st.launch.lds_bytes = std::max(st.launch.lds_bytes, pn_conv3_lds_bytes(cs.ks, cs.wp, cs.nbuf, cs.rpg));
+            }
+            st.launch.lds_bytes = std::max<size_t>(st.launch.lds_bytes, 4 * 7 * 1024 + 1024);   // the tail's fragment image
+        }
         if (c0.kern == 4) st.launch.lds_bytes = 0;                        // conv4_launch knows its own size
         st.launch.probs_dev = st.dev_probs;
         PN_HIP_CHECK(n->ctx, hipMemcpyAsync(st.dev_probs, st.host_probs.data(), st.host_probs.size() * sizeof(ConvProblem),
@@ -907,6 +923,7 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
                 char lb[96];
                 const ConvLaunch &cl = st.launch;
                 if (cl.kern == 4) snprintf(lb, sizeof lb, "conv4_kernel");
+                else if (cl.kern == 3 && cl.mix) snprintf(lb, sizeof lb, "conv3_mix_kernel");
                 else if (cl.kern == 3) snprintf(lb, sizeof lb, "conv3_kernel<%d, %d, %d, %d, %d, %d>", cl.ks, cl.wc, cl.wp, cl.nbuf, cl.pt, cl.rpg);
                 else snprintf(lb, sizeof lb, "conv_mfma_kernel<%d, %d, %d, %d, %d>", cl.prec, cl.ks, cl.stride, cl.pitch, cl.cfg);
                 pr->label = lb;
