@@ -245,8 +245,10 @@ def launcher_dry_run(args):
     t = torch.tensor([rank + 1], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(t)
+    # the same call main() makes after the timed region, on EVERY rank (a collective entered by rank 0 alone hangs the job)
+    chk = dist_check(torch.device("cpu"), world, rank, dist) if world > 1 else None
     if rank == 0:
-        print(json.dumps({"launcher_dry_run": True, "n_gpus": world, "rank_sum": int(t.item()), "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}))
+        print(json.dumps({"launcher_dry_run": True, "n_gpus": world, "rank_sum": int(t.item()), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "dist": chk}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -259,6 +261,10 @@ def dist_check(dev, world, rank, dist):
     from popnet_amd import _lib
     from popnet_amd.pipeline import gather_records
     from popnet_amd.train import TrainEngine
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
     item = _lib.POSE_WIRE_DTYPE.itemsize
     n_frames = 96 * world
     g = torch.Generator(device="cpu").manual_seed(11)
@@ -266,17 +272,17 @@ def dist_check(dev, world, rank, dist):
     mine = allrec[rank::world].to(dev)
     t0 = time.perf_counter()
     got = gather_records(mine, n_frames, rank, world)
-    torch.cuda.synchronize()
+    sync()
     t_gather = time.perf_counter() - t0
     gather_ok = bool(torch.equal(got.cpu(), allrec))
     flat = torch.randn(5525816, generator=g).to(dev)               # the trainer's flat gradient buffer: 22 MB
     ref = flat.clone()
     TrainEngine.reduce_flat_gradient(flat, world, None, force=True)
-    torch.cuda.synchronize()
+    sync()
     t1 = time.perf_counter()
     for _ in range(5):
         TrainEngine.reduce_flat_gradient(flat, world, None, force=True)
-    torch.cuda.synchronize()
+    sync()
     t_ar = (time.perf_counter() - t1) / 5
     # world replicas of the same buffer summed 6 times: flat == ref * world ** 6 exactly in fp32 for world = 1, 2, 4, 8
     allreduce_ok = bool(torch.equal(flat, ref * float(world) ** 6))
@@ -544,12 +550,14 @@ def main():
             dist.destroy_process_group()
         return
     legs = pipelined_leg(args, dev, world, rank, dist, args.net, args.precision, want_h2d=not args.no_h2d, dist_active=dist_active)
+    # collectives: EVERY rank takes part (rank 0 alone would wait for the others forever)
+    dist_res = dist_check(dev, world, rank, dist) if dist_active else None
     if rank == 0:
         out = legs["out"]
         engine = legs["engine"]
         default_line = world == 1 and args.net == "rtpose" and not args.no_extras
-        if dist_active:
-            out["dist"] = dist_check(dev, world, rank, dist)
+        if dist_res is not None:
+            out["dist"] = dist_res
         if default_line:
             out["mpaug_parse"] = mpaug_parse_leg(engine)
             out["precision_modes"] = precision_modes_leg(dev)

@@ -110,6 +110,8 @@ def test_bench_self_launches_ranks_from_a_bare_shell():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["launcher_dry_run"] and out["n_gpus"] == 2 and out["rank_sum"] == 3
+    # bench.py's collective check (gather_records + the 22 MB gradient all-reduce) entered by BOTH ranks, as main() does
+    assert out["dist"]["world_size"] == 2 and out["dist"]["gather_records_ok"] and out["dist"]["flat_gradient_allreduce_ok"], out["dist"]
 
 
 def test_torchrun_command_shape():
