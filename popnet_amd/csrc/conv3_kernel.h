@@ -67,7 +67,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // native vect
 // TAIL: the instantiation whose blocks run a second 1x1 convolution on their 128-channel output tile instead of storing it
 // (ConvProblem::tail_w; its own instantiation so that the plain kernel's register allocation is untouched: with both epilogues
 // in one body the 128-register 1x1 kernel spilled 41 VGPRs)
-template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7, bool TAIL = false>
+template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7, int TAIL = 0>
 __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
     typedef __bf16 T;
     typedef Elem<PN_PREC_BF16>::Frag Frag;
@@ -117,10 +117,13 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
     const int tile = tt % P.tiles_per_img;
     const int b = tt / P.tiles_per_img;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const int oy0 = ty * P.R, ox0 = tx * P.Wt;
-    const int R = min(P.R, P.Ho - oy0);
+    // TAIL == 2 (fused average pool): the block computes the (2 * 3 + 1) x (2 * 7 + 1) patch of the 1x1 convolution's output that its 3 x 7
+    // pooled pixels need, origin one row / column before the first window (rows and columns outside the map: zero-page input,
+    // masked out of the window sums); neighbouring blocks recompute the shared row and column
+    const int oy0 = TAIL == 2 ? ty * 6 - 1 : ty * P.R, ox0 = TAIL == 2 ? tx * 14 - 1 : tx * P.Wt;
+    const int R = TAIL == 2 ? 7 : min(P.R, P.Ho - oy0);
     const int Wo = P.Wo;
-    const int Wc = min(P.Wt, Wo - ox0);
+    const int Wc = TAIL == 2 ? 15 : min(P.Wt, Wo - ox0);
     const int npix = R * Wc;
     const int HC = Wc + KS - 1;
     const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
@@ -307,7 +310,75 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
     // (bias + activation + bf16, exactly what the epilogue below would store) are channels 32 wc + 8 q .. + 7 of pixel c: the B
     // fragment of the second convolution's k-step wc.  The four waves park their fragments in LDS, then each wave runs the
     // chained MFMAs of its pixel tiles over k-steps 0..3 -- the same accumulation chain as the two-launch path, bit for bit.
-    if constexpr (TAIL) {
+    if constexpr (TAIL == 2) {
+        // ---- fused AvgPool2d(3, 2, 1) (ConvProblem::pool_tail, net.hip::fuse_pool_tails; rtpose_light3d.py:157-158): the block's
+        // finished values (bias + activation + bf16: what the epilogue would store, what pool_kernel would read back) are parked in
+        // LDS in the layout of the 1x1 tail, then every thread sums the nine taps of its pooled pixels x 8 channels in pool_kernel's
+        // order (row-major taps, fp32, a tap outside the map adds 0, one division by 9) -- bit-identical to the two-launch path;
+        // the full-resolution map is never written.
+        static_assert(KS == 1 && WC == 4 && WP == 1 && PT == 7 && RPG == 8, "the fused pool is built for the 128-cout 1x1 block on a 7 x 15 patch");
+        constexpr int LC = CT * 4;
+        const int cw = wc * (CT * 16) + LC * q;
+        float bias[LC];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const f32x4 b4 = *reinterpret_cast<const PN_GLOBAL f32x4 *>((const PN_GLOBAL float *)P.bias + cw + 4 * ct);
+            bias[4 * ct + 0] = b4[0]; bias[4 * ct + 1] = b4[1]; bias[4 * ct + 2] = b4[2]; bias[4 * ct + 3] = b4[3];
+        }
+        const int act = P.act;
+        __syncthreads();                                 // every wave is done reading the halo image: its space becomes the parked tile
+        auto park = [&](auto actc) {
+            constexpr int ACT = decltype(actc)::value;
+#pragma clang loop unroll(full)
+            for (int pt = 0; pt < PT; ++pt) {
+                T ov[LC];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[ct][pt][i] + bias[4 * ct + i];
+                        if (ACT == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (ACT == PN_ACT_LEAKY) v = v > 0.f ? v : v * 0.1f;
+                        ov[4 * ct + i] = (T)v;
+                    }
+                *reinterpret_cast<u32x4 *>(smem + ((wc * PT + pt) * 64 + lane) * 16) = *reinterpret_cast<u32x4 *>(ov);
+            }
+        };
+        if (act == PN_ACT_RELU) park(std::integral_constant<int, PN_ACT_RELU>{});
+        else if (act == PN_ACT_LEAKY) park(std::integral_constant<int, PN_ACT_LEAKY>{});
+        else park(std::integral_constant<int, PN_ACT_NONE>{});
+        __syncthreads();
+        const int Hp = (P.Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1;          // pooled map
+        PN_GLOBAL T *pout = (PN_GLOBAL T *)P.tail_out + P.tail_out_coff;
+        for (int item = tid; item < 3 * 7 * 16; item += 256) {
+            const int g8 = item & 15, pp = item >> 4, pi = pp / 7, pj = pp - pi * 7;
+            const int py = ty * 3 + pi, px = tx * 7 + pj;
+            if (py >= Hp || px >= Wp) continue;
+            const int wq = g8 >> 2, qq = g8 & 3;                             // channels 8 g8 .. + 7 live in wave wq's fragments, lane quarter qq
+            float a8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a8[k] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ry = 2 * pi + ky, rx = 2 * pj + kx;            // patch coordinates; map coordinates oy0 + ry, ox0 + rx
+                    const bool ok = (unsigned)(oy0 + ry) < (unsigned)P.Ho && (unsigned)(ox0 + rx) < (unsigned)Wo;
+                    const int slot = ry * 15 + rx;
+                    T tv[8];
+                    *reinterpret_cast<u32x4 *>(tv) = *reinterpret_cast<const u32x4 *>(smem + ((wq * PT + (slot >> 4)) * 64 + qq * 16 + (slot & 15)) * 16);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a8[k] += ok ? (float)tv[k] : 0.f;
+                }
+            T o8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o8[k] = (T)(a8[k] / 9.0f);
+            *reinterpret_cast<PN_GLOBAL u32x4 *>(pout + ((size_t)(b * Hp + py) * Wp + px) * (size_t)P.tail_out_cs + g8 * 8) = *reinterpret_cast<u32x4 *>(o8);
+        }
+        PN_STAMP_AT(12);
+        return;
+    }
+    if constexpr (TAIL == 1) {
         static_assert(KS == 1 && WC == 4 && WP == 1 && PT == 7, "the fused tail is built for the 128-cout 1x1 block");
         {
             constexpr int LC = CT * 4;
@@ -569,7 +640,7 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
     PN_STAMP_AT(12);
 }
 
-template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7, bool TAIL = false>
+template <int KS, int WC, int WP, int NBUF, int PT, int RPG = PT * 4 / 7, int TAIL = 0>
 __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CONV3_OCC)) void conv3_kernel(const ConvProblem *__restrict__ probs) {
     conv3_body<KS, WC, WP, NBUF, PT, RPG, TAIL>(probs[blockIdx.y]);
 }
@@ -582,11 +653,11 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
 template <int UNUSED = 0>      // a template only so that the header can hold it: instantiated in conv3_inst_0.hip alone
 __global__ __launch_bounds__(256, PN_CONV3_OCC) void conv3_mix_kernel(const ConvProblem *__restrict__ probs) {
     const ConvProblem &P = probs[blockIdx.y];
-    if (P.tail_w) conv3_body<1, 4, 1, 1, 7, 4, true>(P);
-    else conv3_body<3, 4, 1, 1, 7, 4, false>(P);
+    if (P.tail_w) conv3_body<1, 4, 1, 1, 7, 4, 1>(P);
+    else conv3_body<3, 4, 1, 1, 7, 4, 0>(P);
 }
 
-template <int KS, int WC, int WP, int NBUF, int PT = 7, int RPG = PT * 4 / 7, bool TAIL = false>
+template <int KS, int WC, int WP, int NBUF, int PT = 7, int RPG = PT * 4 / 7, int TAIL = 0>
 static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
     auto kern = conv3_kernel<KS, WC, WP, NBUF, PT, RPG, TAIL>;
     if (L.lds_bytes > 48 * 1024) {
@@ -604,7 +675,9 @@ static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream
 #define PN3_CASE(KS, WC, WP, NB) \
     if (!L.mix && L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && !L.tail) return conv3_launch_one<KS, WC, WP, NB>(ctx, L, stream);
 #define PN3_CASE_TAIL(KS, WC, WP, NB) \
-    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && L.tail) return conv3_launch_one<KS, WC, WP, NB, 7, 4, true>(ctx, L, stream);
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 4 && L.tail == 1) return conv3_launch_one<KS, WC, WP, NB, 7, 4, 1>(ctx, L, stream);
+#define PN3_CASE_POOLTAIL(KS, WC, WP, NB) \
+    if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == 7 && L.rpg == 8 && L.tail == 2) return conv3_launch_one<KS, WC, WP, NB, 7, 8, 2>(ctx, L, stream);
 #define PN3_CASE_PT(KS, WC, WP, NB, PT_) \
     if (L.ks == KS && L.wc == WC && L.wp == WP && L.nbuf == NB && L.pt == PT_ && L.rpg == PT_ * 4 / 7) return conv3_launch_one<KS, WC, WP, NB, PT_>(ctx, L, stream);
 #define PN3_CASE_RPG(KS, WC, WP, NB, RPG_) \

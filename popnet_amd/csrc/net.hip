@@ -59,6 +59,8 @@ struct ConvSpec {
     bool fused_away = false;  // this conv runs as the tail of another one: it has no launch of its own
     void *tail_wpack = nullptr;
     float *tail_bias = nullptr;
+    bool pool_tail = false;   // fuse_pool_tails: the AvgPool2d(3, 2, 1) that follows runs inside this conv's launch (conv3_kernel<1, 4, 1, 1, 7, 8, 2>)
+    int pool_out_buf = -1, pool_out_coff = 0;
 };
 
 struct Step {
@@ -447,7 +449,7 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
             if (used[j]) continue;
-            const bool same = (b.tail_conv >= 0) == (a.tail_conv >= 0) && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
+            const bool same = (b.tail_conv >= 0) == (a.tail_conv >= 0) && b.pool_tail == a.pool_tail && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
                 (a.kern == 4 || (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg));
             const bool mixed = !no_mix && mixable(a) && mixable(b) && b.R == a.R && b.Wt == a.Wt;
             if (same || mixed) {
@@ -644,6 +646,46 @@ void fuse_1x1_tails(pn_net *n, std::vector<std::vector<int>> &levels) {
     levels.erase(std::remove_if(levels.begin(), levels.end(), [](const std::vector<int> &l) { return l.empty(); }), levels.end());
 }
 
+
+// `1x1 128 -> 128 + BN + ReLU` followed by AvgPool2d(3, 2, 1) (model0.conv2 / bn2 / relu -> avgpool, rtpose_light3d.py:154-158): the
+// convolution is per pixel, so a block can compute exactly the 7 x 15 patch that 3 x 7 pooled pixels need and sum the windows
+// from LDS (conv3_kernel.h, TAIL == 2).  The pool launch and the full-resolution map (25.7 MB written and read back at B = 32)
+// disappear; blocks recompute one shared row and column (25 % more matrix work on a bandwidth-bound layer).  Same values, same
+// summation order as the two launches: bit-identical (POPNET_NO_POOLFUSE=1 keeps them).  bf16 only.
+void fuse_pool_tails(pn_net *n, std::vector<std::vector<int>> &levels) {
+    if (n->prec != PN_PREC_BF16 || n->x3 || getenv("POPNET_NO_POOLFUSE") || getenv("POPNET_NO_CONV3")) return;
+    for (size_t li = 0; li + 1 < levels.size(); ++li) {
+        if (levels[li].size() != 1 || levels[li][0] < 0) continue;
+        const std::vector<int> &pl = levels[li + 1];
+        if (pl.empty() || pl[0] != -1 || pl[1] != 0) continue;                 // {-1, mode 0 = average 3x3 s2, in, out, C, coff}
+        ConvSpec &a = n->convs[levels[li][0]];
+        if (a.kern != 3 || a.ks != 1 || a.stride != 1 || a.cout != 128 || a.wc != 4 || a.wp != 1 || a.res_buf >= 0 || a.nchw_slot >= 0 || a.out_buf < 0 || a.out_coff != 0 ||
+            a.tail_conv >= 0 || (a.act != PN_ACT_NONE && a.act != PN_ACT_RELU && a.act != PN_ACT_LEAKY))
+            continue;
+        if (pl[2] != a.out_buf || pl[4] != 128 || (pl[5] & 7)) continue;
+        bool other_reader = false, rewritten = false;                          // nothing else may read the full-resolution map
+        for (size_t lj = li + 2; lj < levels.size() && !rewritten; ++lj) {
+            if (levels[lj].empty()) continue;
+            if (levels[lj][0] == -1) {
+                if (levels[lj][2] == a.out_buf) other_reader = true;
+                if (levels[lj][3] == a.out_buf) rewritten = true;
+                continue;
+            }
+            for (size_t k = levels[lj][0] == -2 ? 1 : 0; k < levels[lj].size(); ++k) {
+                const ConvSpec &c = n->convs[levels[lj][k]];
+                if (c.in_buf == a.out_buf || c.res_buf == a.out_buf) other_reader = true;
+            }
+            for (size_t k = levels[lj][0] == -2 ? 1 : 0; k < levels[lj].size(); ++k)
+                if (n->convs[levels[lj][k]].out_buf == a.out_buf) rewritten = true;
+        }
+        if (other_reader) continue;
+        a.pool_tail = true;
+        a.pool_out_buf = pl[3]; a.pool_out_coff = pl[5];
+        a.rpg = 8; a.nbuf = 1;                                                 // 8-row image: the 7 patch rows
+        levels.erase(levels.begin() + li + 1);
+    }
+}
+
 int pack_tail(pn_net *n, ConvSpec &a) {
     pn_ctx *ctx = n->ctx;
     const ConvSpec &b = n->convs[a.tail_conv];
@@ -747,6 +789,7 @@ int build_rtpose(pn_net *n) {
     for (auto &cs : n->convs) n->flops_per_frame += cs.flops;
     fuse_basic_blocks(n, levels);
     fuse_1x1_tails(n, levels);
+    fuse_pool_tails(n, levels);
     for (auto &cs : n->convs)
         if (cs.tail_conv >= 0)
             if (int rc = pack_tail(n, cs)) return rc;
@@ -821,7 +864,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         const int BC = c0.kern == 4 ? 128 : (c0.kern == 3 ? c0.wc * 32 : pn_cfg_couts(c0.cfg));
         st.host_probs.clear();
         int max_blocks = 0;
-        bool two_bufs = false, has_tail = false;
+        bool two_bufs = false, has_tail = false, pool_tail = false;
         for (int id : st.conv_ids) {
             const ConvSpec &cs = n->convs[id];
             const Buf &ib = n->bufs[cs.in_buf];
@@ -854,6 +897,15 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
             P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
             P.in_zero_off = (unsigned)((size_t)n->max_batch * ib.H * ib.W * ib.C * es);      // zero page behind every activation buffer
+            if (cs.pool_tail) {                        // 3 x 7 pooled pixels per block, the pooled map as the only output
+                const Buf &pb = n->bufs[cs.pool_out_buf];
+                P.tiles_x = (pb.W + 6) / 7;
+                P.tiles_per_img = ((pb.H + 2) / 3) * P.tiles_x;
+                P.nblocks = B * P.tiles_per_img * P.cout_blocks;
+                P.tail_out = pb.p; P.tail_out_cs = pb.C; P.tail_out_coff = cs.pool_out_coff;
+                P.out = nullptr;
+                pool_tail = true;
+            }
             if (cs.tail_conv >= 0) {
                 const ConvSpec &tb = n->convs[cs.tail_conv];
                 P.tail_w = cs.tail_wpack; P.tail_bias = cs.tail_bias; P.tail_cout = tb.cout; P.tail_act = tb.act;
@@ -873,9 +925,9 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         st.launch.lds_bytes = pn_conv_lds_bytes(n->prec, c0.ks, c0.stride, c0.pitch, c0.R) * (two_bufs ? 2 : 1);
         st.launch.kern = c0.kern; st.launch.wc = c0.wc; st.launch.wp = c0.wp; st.launch.nbuf = c0.nbuf; st.launch.pt = c0.pt; st.launch.rpg = c0.rpg;
         if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf, c0.rpg);
-        st.launch.tail = (c0.kern == 3 && has_tail) ? 1 : 0;
+        st.launch.tail = (c0.kern == 3 && has_tail) ? 1 : (c0.kern == 3 && pool_tail) ? 2 : 0;
         st.launch.mix = 0;
-        if (st.launch.tail) {
+        if (st.launch.tail == 1) {
             for (int id : st.conv_ids) {
                 const ConvSpec &cs = n->convs[id];
                 if (cs.tail_conv < 0) st.launch.mix = 1;                                               // 3x3 siblings in the launch: conv3_mix_kernel

@@ -118,7 +118,7 @@ struct ConvLaunch {
     int pitch;     // LDS halo row pitch in pixels (multiple of 8, >= halo columns)
     int cfg;       // pn_conv_cfg
     int kern = 0, wc = 0, wp = 0, nbuf = 0, pt = 7, rpg = 4;   // kern 3: conv3_kernel<ks, wc, wp, nbuf, pt, rpg>
-    int tail = 0;            // kern 3: every problem of the launch carries a fused 1x1 tail (ConvProblem::tail_w)
+    int tail = 0;            // kern 3: 1 = every problem of the launch carries a fused 1x1 tail (ConvProblem::tail_w); 2 = a fused average pool (net.hip::fuse_pool_tails)
     int mix = 0;             // kern 3: 3x3 problems and fused-tail 1x1 problems share the launch (conv3_mix_kernel)
     int nprob;
     int max_blocks;          // max nblocks over the group
