@@ -645,8 +645,9 @@ __global__ __launch_bounds__(WC * WP * 64, PT == 14 ? 2 : (NBUF == 2 ? 3 : PN_CO
     conv3_body<KS, WC, WP, NBUF, PT, RPG, TAIL>(probs[blockIdx.y]);
 }
 
-// One launch for the two kinds of 128-cout blocks a stage's fourth level holds (rtpose_light3d.py:263-309): the 3x3 convolutions of
-// the heat / depth branches and the fused 1x1 + 1x1 tail of the PAF branch.  Alone, neither fills the chip (448 and 224 blocks of
+// One launch for the kinds of 128-cout blocks a level holds side by side: a stage's fourth level (rtpose_light3d.py:263-309) = the 3x3
+// convolutions of the heat / depth branches + the fused 1x1 + 1x1 tail of the PAF branch; layer2's first level = the BasicBlock's
+// first 3x3 + its 1x1 shortcut.  Alone, neither fills the chip (448 and 224 blocks of
 // 4 waves for 1 024 SIMDs x 4 slots) and each pays its own ramp, drain and kernel boundary; a block picks its body by a scalar
 // test of its problem (same block shape, same 128-register budget; LDS = the larger of the two).  Same code per block as the
 // separate launches: results are bit-identical (POPNET_NO_MIX=1 keeps the two launches).
@@ -654,6 +655,7 @@ template <int UNUSED = 0>      // a template only so that the header can hold it
 __global__ __launch_bounds__(256, PN_CONV3_OCC) void conv3_mix_kernel(const ConvProblem *__restrict__ probs) {
     const ConvProblem &P = probs[blockIdx.y];
     if (P.tail_w) conv3_body<1, 4, 1, 1, 7, 4, 1>(P);
+    else if (P.ks == 1) conv3_body<1, 4, 1, 1, 7, 4, 0>(P);      // a plain 1x1 sibling (the 1x1 shortcut next to a BasicBlock's first 3x3, resnet.py:59-77)
     else conv3_body<3, 4, 1, 1, 7, 4, 0>(P);
 }
 

@@ -54,7 +54,6 @@ struct ConvSpec {
     void *wpack = nullptr;
     float *bias = nullptr;
     double flops = 0;
-    bool embed_center = false; // a 1x1 convolution run as the centre tap of a 3x3 one (zero weights elsewhere), so that it shares the launch of a 3x3 sibling
     int tail_conv = -1;       // fuse_1x1_tails: index of the 1x1 conv (<= 32 couts) that runs inside this conv's launch on its output tile
     bool fused_away = false;  // this conv runs as the tail of another one: it has no launch of its own
     void *tail_wpack = nullptr;
@@ -171,13 +170,9 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const HostTensor *w = find_t(n, cs.w + ".weight");
     if (!w || w->shape.size() != 4)
         return pn_set_error(ctx, PN_ERR_INVALID, "missing conv weight %s.weight", cs.w.c_str());
-    const int cout = (int)w->shape[0], cin_ref = (int)w->shape[1], wks = (int)w->shape[2];
-    // embed_center: the 1x1 shortcut of a BasicBlock as the centre tap of a 3x3 "same" convolution -- eight taps of exact zeros
-    // leave every accumulator unchanged, the two non-zero k-steps come in the 1x1 kernel's order: bit-identical, one launch less
-    if (cs.embed_center && (n->prec == PN_PREC_F32 || getenv("POPNET_NO_EMBED1X1") || getenv("POPNET_NO_CONV3"))) { cs.embed_center = false; cs.ks = 1; }
-    const int ks = cs.embed_center ? 3 : wks;
-    if ((cs.embed_center ? wks != 1 : wks != cs.ks) || (int)w->shape[3] != wks)
-        return pn_set_error(ctx, PN_ERR_INVALID, "%s.weight: kernel %dx%d, expected %d", cs.w.c_str(), wks, (int)w->shape[3], cs.ks);
+    const int cout = (int)w->shape[0], cin_ref = (int)w->shape[1], ks = (int)w->shape[2];
+    if (ks != cs.ks || (int)w->shape[3] != ks)
+        return pn_set_error(ctx, PN_ERR_INVALID, "%s.weight: kernel %dx%d, expected %d", cs.w.c_str(), ks, (int)w->shape[3], cs.ks);
     cs.cout = cout;
     std::vector<int> map = cs.cin_map;
     if (map.empty()) {
@@ -248,8 +243,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     auto wval = [&](int co, int idx, int tap) -> float {      // folded weight of packed input channel idx
         const int ci = map[idx];
         if (co >= cout || ci < 0) return 0.f;
-        if (cs.embed_center && tap != 4) return 0.f;
-        const float v = (float)((double)w->data[((size_t)co * cin_ref + ci) * (wks * wks) + (cs.embed_center ? 0 : tap)] * scale[co]);
+        const float v = (float)((double)w->data[((size_t)co * cin_ref + ci) * (ks * ks) + tap] * scale[co]);
         if (!n->x3) return v;
         uint32_t hb = (uint32_t)f32_to_bf16(v) << 16;
         float hi;
@@ -342,7 +336,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
     if (cs.kern == 3 || cs.kern == 4) {
         cs.pitch = 32;
-        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * (cs.embed_center ? 1 : KK);       // algorithmic FLOPs: the embedded zeros do not count
+        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
         if (cs.out_buf >= 0) {
             const Buf &ob = n->bufs[cs.out_buf];
             if (ob.H != Ho || ob.W != Wo) return pn_set_error(ctx, PN_ERR_INVALID, "%s: output buffer is %dx%d, conv gives %dx%d", cs.w.c_str(), ob.H, ob.W, Ho, Wo);
@@ -444,14 +438,14 @@ void add_conv_level(pn_net *n, const std::vector<int> &ids) {
         // conv3_mix_kernel: the 128-cout 3x3 blocks and the fused-tail 1x1 blocks of a level share one launch
         static const bool no_mix = getenv("POPNET_NO_MIX") != nullptr;
         auto mixable = [](const ConvSpec &c) {
-            return c.kern == 3 && c.stride == 1 && c.wc == 4 && c.wp == 1 && c.nbuf == 1 && c.pt == 7 && c.rpg == 4 && ((c.ks == 3 && c.tail_conv < 0) || (c.ks == 1 && c.tail_conv >= 0));
+            return c.kern == 3 && c.stride == 1 && c.wc == 4 && c.wp == 1 && c.nbuf == 1 && c.pt == 7 && c.rpg == 4 && !c.pool_tail && (c.ks == 3 ? c.tail_conv < 0 : c.ks == 1);
         };
         for (size_t j = i; j < ids.size(); ++j) {
             const ConvSpec &b = n->convs[ids[j]];
             if (used[j]) continue;
             const bool same = (b.tail_conv >= 0) == (a.tail_conv >= 0) && b.pool_tail == a.pool_tail && b.ks == a.ks && b.stride == a.stride && b.pitch == a.pitch && b.R == a.R && b.Wt == a.Wt && b.kern == a.kern &&
                 (a.kern == 4 || (a.kern == 3 ? (b.wc == a.wc && b.wp == a.wp && b.nbuf == a.nbuf && b.pt == a.pt && b.rpg == a.rpg) : b.cfg == a.cfg));
-            const bool mixed = !no_mix && mixable(a) && mixable(b) && b.R == a.R && b.Wt == a.Wt;
+            const bool mixed = !no_mix && mixable(a) && mixable(b) && b.R == a.R && b.Wt == a.Wt && (a.ks == 3 || b.ks == 3 || (a.tail_conv >= 0) == (b.tail_conv >= 0));
             if (same || mixed) {
                 st.conv_ids.push_back(ids[j]);
                 used[j] = true;
@@ -744,8 +738,7 @@ int build_rtpose(pn_net *n) {
     levels.push_back({-1, 0, A1, P1, 64, 0});    // avgpool1 marker: {-1, mode, in, out, C, out_coff}
     // layer2: BasicBlock(64->128) with 1x1 shortcut @ H/4
     level({add_conv(n, "model0.layer2.0.conv1", "model0.layer2.0.bn1", 3, 1, P1, 0, T2, 0, PN_ACT_RELU),
-           add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", 3, 1, P1, 0, D2, 0, PN_ACT_NONE)});
-    n->convs.back().embed_center = true;       // the 1x1 shortcut rides in conv1's 3x3 launch (prepare_conv falls back to a 1x1 launch in fp32 mode)
+           add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", 1, 1, P1, 0, D2, 0, PN_ACT_NONE)});
     level({add_conv(n, "model0.layer2.0.conv2", "model0.layer2.0.bn2", 3, 1, T2, 0, A3, 0, PN_ACT_RELU, D2)});
     level({add_conv(n, "model0.conv2", "model0.bn2", 1, 1, A3, 0, A4, 0, PN_ACT_RELU)});
     levels.push_back({-1, 0, A4, CAT, 128, 0});  // avgpool2 -> feat slice of the concat buffer
@@ -894,6 +887,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.nblocks = B * P.tiles_per_img * P.cout_blocks;
             if (cs.kern == 4) P.nblocks = ((B * P.tiles_per_img + 1) / 2) * P.cout_blocks;      // a block = two strips x 128 couts
             P.ksteps = cs.cin_chunks * cs.ks * cs.ks * 2;
+            P.ks = cs.ks;
             P.lds_buf_bytes = (int)pn_conv_lds_bytes(n->prec, cs.ks, cs.stride, cs.pitch, cs.R);
             P.lds_two = (cs.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
             P.in_zero_off = (unsigned)((size_t)n->max_batch * ib.H * ib.W * ib.C * es);      // zero page behind every activation buffer
@@ -927,13 +921,13 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
         if (c0.kern == 3) st.launch.lds_bytes = pn_conv3_lds_bytes(c0.ks, c0.wp, c0.nbuf, c0.rpg);
         st.launch.tail = (c0.kern == 3 && has_tail) ? 1 : (c0.kern == 3 && pool_tail) ? 2 : 0;
         st.launch.mix = 0;
-        if (st.launch.tail == 1) {
+        if (c0.kern == 3) {
             for (int id : st.conv_ids) {
                 const ConvSpec &cs = n->convs[id];
-                if (cs.tail_conv < 0) st.launch.mix = 1;                                               // 3x3 siblings in the launch: conv3_mix_kernel
+                if (cs.ks != c0.ks || (cs.tail_conv >= 0) != (c0.tail_conv >= 0)) st.launch.mix = 1;   // different bodies in one launch: conv3_mix_kernel
                 st.launch.lds_bytes = std::max(st.launch.lds_bytes, pn_conv3_lds_bytes(cs.ks, cs.wp, cs.nbuf, cs.rpg));
             }
-            st.launch.lds_bytes = std::max<size_t>(st.launch.lds_bytes, 4 * 7 * 1024 + 1024);   // the tail's fragment image
+            if (st.launch.tail == 1) st.launch.lds_bytes = std::max<size_t>(st.launch.lds_bytes, 4 * 7 * 1024 + 1024);   // the tail's fragment image
         }
         if (c0.kern == 4) st.launch.lds_bytes = 0;                        // conv4_launch knows its own size
         st.launch.probs_dev = st.dev_probs;

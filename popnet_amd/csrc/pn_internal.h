@@ -72,6 +72,7 @@ struct ConvProblem {
     int cout_blocks;       // ceil(cout / (WC*CT*16))
     int nblocks;           // B * tiles_per_img * cout_blocks
     int ksteps;            // cin_chunks * KS*KS * 2   (k32 steps per cout tile in wpack)
+    int ks;                // kernel size of this problem (conv3_mix_kernel picks the block's body by it)
     int lds_buf_bytes;     // bytes of one LDS halo image
     int lds_two;           // 1: a second image follows (double-buffered chunks), 0: single image
     unsigned in_zero_off;  // conv3_kernel: byte offset from `in` to >= 16 zero bytes (padding source of the halo DMA)
