@@ -397,8 +397,7 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
     with torch.cuda.stream(streams[0]):
         for k in range(K):
-            nb = engine.preprocess(se.input(0, k % POOL))
-            engine.forward(nb)
+            nb = engine.forward_frames(se.input(0, k % POOL))  # the product path: pre-processing inside the stem launch (bf16 / bf16x3)
             ev[k][0].record()
             if se.wire:
                 engine.parse(nb, se.records(0), se.wires[0])     # post-processing kernels of this step, bracketed on their stream

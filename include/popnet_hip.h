@@ -98,6 +98,18 @@ int pn_rtpose_forward(pn_net *net, const float *x_dev, int B, float *paf_dev, fl
 /* YoloPoseNet.forward (tpm/lib/network/yolo_posenet.py:131-158):
  *   x_dev [B,1,in_h,in_w] -> out [B, A*(5+3J), in_h/16, in_w/16] f32 NCHW, slice casts applied. */
 int pn_yolo_forward(pn_net *net, const float *x_dev, int B, float *out_dev, void *hip_stream);
+/* Frames in (round 3): pn_preprocess + pn_rtpose_forward / pn_yolo_forward as ONE call on the raw depth frames -- the image half of
+ * test-mode KDH3D_Keypoints.__getitem__ (tpm/lib/datasets/datasets_kdh3d_rtpose_mpreal.py:225-246 (CR), data_augmentation_2d3d.py:
+ * 76-89,507-522) followed by model(img) (tpm/evaluate/evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py:171-178 /
+ * evaluation_yolo_posenet_kdh3d_mpreal.py:160-166).  The 7x7 stem computes its input tile with pn_preprocess's arithmetic, so the
+ * maps are bit-identical to the two-call form; the pre-processed [B,1,S,S] tensor is never written.  depth_dev [B,H,W] f16 / f32
+ * metres (device), resized to the square S = in_h = in_w the net was finalized for.  bf16 and bf16x3 nets (the fp32 parity mode
+ * keeps the two calls: PN_ERR_UNSUPPORTED).                                                                                       */
+int pn_rtpose_forward_frames(pn_net *net, const void *depth_dev, int depth_dtype, int B, int H, int W, float depth_max,
+                             float depth_mean, float depth_std, float *paf_dev, float *heat_dev, float *z_dev,
+                             void *hip_stream);
+int pn_yolo_forward_frames(pn_net *net, const void *depth_dev, int depth_dtype, int B, int H, int W, float depth_max,
+                           float depth_mean, float depth_std, float *out_dev, void *hip_stream);
 /* Test/diagnostic: copies a named internal activation of the last forward to the host as
  * f32 NCHW.  Names: "feat" (stem output), "paf1" "heat1" "z1" (stage-1 outputs) for
  * rtpose_light3d; "feat" (layer2 output) for YoloPoseNet.  Synchronises the stream.           */

@@ -91,6 +91,8 @@ _SIGNATURES = {
     "pn_net_finalize": (_i, [_vp, _i, _i, _i, _i]),
     "pn_rtpose_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pn_yolo_forward": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "pn_rtpose_forward_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "pn_yolo_forward_frames": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp]),
     "pn_net_read_activation": (_i, [_vp, C.c_char_p, _i, _vp, _sz, _vp]),
     "pn_net_copy_activation": (_i, [_vp, C.c_char_p, _i, _vp, _vp]),
     "pn_net_flops_per_frame": (_d, [_vp]),

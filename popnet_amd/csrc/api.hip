@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include "pn_internal.h"
+#include "preproc_pixel.h"
 
 template <typename TIN>
 __global__ void preprocess_kernel(const TIN *__restrict__ depth, float *__restrict__ out, int B, int H, int W, int S,
@@ -27,30 +28,7 @@ __global__ void preprocess_kernel(const TIN *__restrict__ depth, float *__restri
     const int dx = (int)(pix - (unsigned)dy * (unsigned)S);
     const size_t gid = (size_t)b * S * S + pix;
 
-    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= (float)sx;
-    if (sx < 0) { sx = 0; fx = 0.f; }
-    if (sx >= W - 1) { sx = W - 1; fx = 0.f; }
-    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
-    int sy = (int)floorf(fy);
-    fy -= (float)sy;
-    int y0 = min(max(sy, 0), H - 1), y1 = min(max(sy + 1, 0), H - 1);
-
-    const TIN *img = depth + (size_t)b * H * W;
-    const float a0 = 1.f - fx, a1 = fx;
-    float h0, h1;
-    if (sx + 1 >= W) {      // HResizeLinear tail: D = S[sx] * 1
-        h0 = (float)img[(size_t)y0 * W + sx];
-        h1 = (float)img[(size_t)y1 * W + sx];
-    } else {
-        h0 = (float)img[(size_t)y0 * W + sx] * a0 + (float)img[(size_t)y0 * W + sx + 1] * a1;
-        h1 = (float)img[(size_t)y1 * W + sx] * a0 + (float)img[(size_t)y1 * W + sx + 1] * a1;
-    }
-    float v = h0 * (1.f - fy) + h1 * fy;
-    if (v < 0.f) v = 0.f;
-    if (v > dmax) v = dmax;
-    out[gid] = (v - mean) / stdv;
+    out[gid] = pn_preproc_pixel(depth + (size_t)b * H * W, H, W, dy, dx, scale_x, scale_y, dmax, mean, stdv);
 }
 
 extern "C" {

@@ -8,6 +8,7 @@
 //          nn.MaxPool2d(3, 2, 1)                                   yolo_posenet.py:37
 //          nn.MaxPool2d(2, 2)                                      yolo_posenet.py:118
 #include "pn_internal.h"
+#include "preproc_pixel.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -89,10 +90,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int stem_u32x4;
 
 // X3 (bf16x3 mode): the input patch is kept as hi + lo bf16 parts, the weights as hi + lo fragments (16 instead of 8), and
 // every product is x_hi w_hi + x_lo w_hi + x_hi w_lo -- the stem must not round the depth frame to 8 significant bits.
-template <bool X3>
+// SRC: 0 = x is the pre-processed [B, 1, H, W] f32 input; 1 / 2 = the kernel reads the RAW depth frames (f16 / f32) and computes
+// every pixel of its input tile with pn_preproc_pixel -- pn_preprocess's own arithmetic, so the tile holds the same floats:
+// the pre-processing launch and the 6.4 MB it writes and the stem reads back (B = 32) disappear (pn_*_forward_frames).
+template <bool X3, int SRC = 0>
 __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wfrag,
                                                             const float *__restrict__ bias, __bf16 *__restrict__ out,
-                                                            int H, int W, int Ho, int Wo, int out_cs, int split) {
+                                                            int H, int W, int Ho, int Wo, int out_cs, int split, PnFrameSrc src) {
     __shared__ __attribute__((aligned(16))) __bf16 tile[38 * STEM_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 tile_lo[X3 ? 38 * STEM_PITCH : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,7 +104,20 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
     const int b = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 4;
     const float *xb = x + (size_t)b * H * W;
-    if ((W & 3) == 0) {
+    if (SRC != 0) {
+        for (int i = tid; i < 38 * 38; i += 256) {
+            const int r = i / 38, cc = i - r * 38;
+            const int iy = iy0 + r, ix = ix0 + cc;
+            float v = 0.f;
+            if (r < 37 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                if (SRC == 1) v = pn_preproc_pixel((const _Float16 *)src.frames + (size_t)b * src.H * src.W, src.H, src.W, iy, ix, src.scale_x, src.scale_y, src.dmax, src.mean, src.stdv);
+                else v = pn_preproc_pixel((const float *)src.frames + (size_t)b * src.H * src.W, src.H, src.W, iy, ix, src.scale_x, src.scale_y, src.dmax, src.mean, src.stdv);
+            }
+            const __bf16 vh = (__bf16)v;
+            tile[r * STEM_PITCH + cc] = vh;
+            if (X3) tile_lo[r * STEM_PITCH + cc] = (__bf16)(v - (float)vh);
+        }
+    } else if ((W & 3) == 0) {
         // 16-byte loads: ix0 = 32 k - 4 and W are multiples of 4, so a group of four columns is entirely inside or entirely
         // outside the frame; 380 vector loads per block instead of 1 444 scalar ones (round 3: the stem was 25 us of a 0.49 ms
         // step with the texture addresser 7x as busy as the matrix pipe, and not hidden behind the other streams)
@@ -188,12 +205,23 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
 }
 
 int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const void *wfrag, const float *bias, void *out,
-                   int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream) {
+                   int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream, const PnFrameSrc *src) {
     dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B), block(256);
+    const PnFrameSrc none = {};
+    if (src) {                           // raw depth frames in (matrix-core stems only: net.hip refuses the fp32 net)
+        const bool f16 = src->dtype == PN_DEPTH_F16;
+        if (prec == PN_PREC_BF16 && f16) hipLaunchKernelGGL((stem7x7_mfma_kernel<false, 1>), grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split, *src);
+        else if (prec == PN_PREC_BF16) hipLaunchKernelGGL((stem7x7_mfma_kernel<false, 2>), grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split, *src);
+        else if (prec == PN_PREC_BF16X3 && f16) hipLaunchKernelGGL((stem7x7_mfma_kernel<true, 1>), grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split, *src);
+        else if (prec == PN_PREC_BF16X3) hipLaunchKernelGGL((stem7x7_mfma_kernel<true, 2>), grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split, *src);
+        else return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "the frames-in stem is built for the bf16 and bf16x3 nets");
+        PN_HIP_CHECK(ctx, hipGetLastError());
+        return PN_OK;
+    }
     if (prec == PN_PREC_BF16)
-        hipLaunchKernelGGL(stem7x7_mfma_kernel<false>, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
+        hipLaunchKernelGGL((stem7x7_mfma_kernel<false, 0>), grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split, none);
     else if (prec == PN_PREC_BF16X3)     // split input and split weights on the matrix cores, split bf16 output
-        hipLaunchKernelGGL(stem7x7_mfma_kernel<true>, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split);
+        hipLaunchKernelGGL((stem7x7_mfma_kernel<true, 0>), grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, out_cs, split, none);
     else
         hipLaunchKernelGGL(stem7x7_kernel<float>, grid, block, 0, stream, x, w, bias, (float *)out, H, W, Ho, Wo, out_cs, 0);
     PN_HIP_CHECK(ctx, hipGetLastError());

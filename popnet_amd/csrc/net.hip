@@ -20,6 +20,7 @@
 #include <memory>
 #include <vector>
 #include "pn_internal.h"
+#include "preproc_pixel.h"
 
 namespace {
 
@@ -115,6 +116,9 @@ struct pn_net {
     std::map<std::string, std::pair<std::pair<double, int64_t>, double>> prof_by_kernel;   // label -> ((ms, launches), flops), filled by profile_end
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
+    // pn_*_forward_frames: the stem reads the raw depth frames (frame_src.frames != nullptr during that call)
+    PnFrameSrc frame_src = {};
+    const void *last_frames = nullptr;
 
     size_t esize() const { return prec == PN_PREC_BF16 ? 2 : 4; }
 };
@@ -992,7 +996,8 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         }
         if (st.type == Step::STEM) {
             const Buf &ob = n->bufs[st.out_buf];
-            rc = pn_launch_stem(ctx, n->x3 ? PN_PREC_BF16X3 : n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, n->x3 ? ob.plane : 0, stream);
+            rc = pn_launch_stem(ctx, n->x3 ? PN_PREC_BF16X3 : n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, n->x3 ? ob.plane : 0, stream,
+                                n->frame_src.frames ? &n->frame_src : nullptr);
         } else if (st.type == Step::POOL) {
             const Buf &ib = n->bufs[st.in_buf], &ob = n->bufs[st.out_buf];
             rc = pn_launch_pool(ctx, n->prec, st.mode, ib.p, ob.p, B, ib.H, ib.W, st.C, ib.C, ob.C, st.out_coff, n->x3 ? ib.plane : 0, n->x3 ? ob.plane : 0, stream);
@@ -1097,6 +1102,47 @@ int pn_yolo_forward(pn_net *n, const float *x_dev, int B, float *out_dev, void *
     if (!x_dev || !out_dev) return pn_set_error(n->ctx, PN_ERR_INVALID, "null device pointer");
     n->nchw_ptr[3] = out_dev;
     return run_forward(n, x_dev, B, (hipStream_t)hip_stream);
+}
+
+// frames in: the 7x7 stem computes its input tile from the raw depth frames with pn_preprocess's arithmetic (preproc_pixel.h)
+static int forward_frames(pn_net *n, const void *depth_dev, int depth_dtype, int B, int H, int W, float depth_max, float depth_mean, float depth_std,
+                          hipStream_t stream) {
+    pn_ctx *ctx = n->ctx;
+    if (!depth_dev || H < 2 || W < 2) return pn_set_error(ctx, PN_ERR_INVALID, "forward_frames: bad arguments");
+    if (depth_dtype != PN_DEPTH_F16 && depth_dtype != PN_DEPTH_F32) return pn_set_error(ctx, PN_ERR_INVALID, "forward_frames: unknown depth dtype %d", depth_dtype);
+    if (!n->finalized) return pn_set_error(ctx, PN_ERR_STATE, "pn_net_finalize has not been called");
+    if (n->prec != PN_PREC_BF16) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "the frames-in forward is built for the bf16 and bf16x3 nets (fp32: pn_preprocess + pn_*_forward)");
+    if (n->in_h != n->in_w) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "the frames-in forward resizes to a square input (net finalized for %dx%d)", n->in_h, n->in_w);
+    const int S = n->in_h;
+    if (W == 2 * S && H == 2 * S)   // as pn_preprocess: cv::resize switches to INTER_AREA at exactly 2x decimation
+        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "forward_frames: %dx%d -> %d is an exact 2x decimation, where cv2.resize(INTER_LINEAR) runs INTER_AREA instead: not built", W, H, S);
+    PnFrameSrc fs;
+    fs.frames = depth_dev; fs.dtype = depth_dtype; fs.H = H; fs.W = W;
+    const double inv_x = (double)S / (double)W, inv_y = (double)S / (double)H;
+    fs.scale_x = 1.0 / inv_x; fs.scale_y = 1.0 / inv_y;                    // as cv::resize computes them (pn_preprocess)
+    fs.dmax = depth_max; fs.mean = depth_mean; fs.stdv = depth_std;
+    n->frame_src = fs;
+    const int rc = run_forward(n, nullptr, B, stream);
+    n->frame_src.frames = nullptr;
+    return rc;
+}
+
+int pn_rtpose_forward_frames(pn_net *n, const void *depth_dev, int depth_dtype, int B, int H, int W, float depth_max, float depth_mean, float depth_std,
+                             float *paf_dev, float *heat_dev, float *z_dev, void *hip_stream) {
+    if (!n) return PN_ERR_INVALID;
+    if (n->kind != PN_NET_RTPOSE_LIGHT3D) return pn_set_error(n->ctx, PN_ERR_INVALID, "not an rtpose_light3d net");
+    if (!paf_dev || !heat_dev || !z_dev) return pn_set_error(n->ctx, PN_ERR_INVALID, "null device pointer");
+    n->nchw_ptr[0] = paf_dev; n->nchw_ptr[1] = heat_dev; n->nchw_ptr[2] = z_dev;
+    return forward_frames(n, depth_dev, depth_dtype, B, H, W, depth_max, depth_mean, depth_std, (hipStream_t)hip_stream);
+}
+
+int pn_yolo_forward_frames(pn_net *n, const void *depth_dev, int depth_dtype, int B, int H, int W, float depth_max, float depth_mean, float depth_std,
+                           float *out_dev, void *hip_stream) {
+    if (!n) return PN_ERR_INVALID;
+    if (n->kind != PN_NET_YOLO_POSENET) return pn_set_error(n->ctx, PN_ERR_INVALID, "not a YoloPoseNet net");
+    if (!out_dev) return pn_set_error(n->ctx, PN_ERR_INVALID, "null device pointer");
+    n->nchw_ptr[3] = out_dev;
+    return forward_frames(n, depth_dev, depth_dtype, B, H, W, depth_max, depth_mean, depth_std, (hipStream_t)hip_stream);
 }
 
 int pn_net_copy_activation(pn_net *n, const char *name, int B, float *dev_out, void *hip_stream) {

@@ -149,8 +149,9 @@ int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 
 // stem: 7x7 stride-2 pad-3, Cin = 1, fused folded-BN bias + ReLU.  x NCHW f32 [B,1,H,W] ->
 // NHWC T [B,Ho,Wo,64].  w [49][64] f32 (tap-major) for the fp32 VALU kernel, wfrag = the same weights as
 // 8 bf16 MFMA A-fragments (see stem7x7_mfma_kernel) for bf16 mode, bias [64].
+struct PnFrameSrc;       // preproc_pixel.h: raw depth frames + the pre-processing constants (nullptr = x is the pre-processed input)
 int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const void *wfrag, const float *bias,
-                   void *out, int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream);
+                   void *out, int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream, const PnFrameSrc *src = nullptr);
 
 // pooling on NHWC T.  mode 0: avg 3x3 s2 p1 (count_include_pad), 1: max 3x3 s2 p1, 2: max 2x2 s2.
 int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, int B, int H, int W,

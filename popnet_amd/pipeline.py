@@ -24,6 +24,7 @@ from .utils.paf_to_pose import make_parse_cfg
 
 
 import os as _os
+_NO_FRAMES_IN = bool(_os.environ.get("POPNET_NO_FRAMES_IN"))     # experiment switch: pn_preprocess + pn_*_forward as two calls in every precision
 _ABLATE_SKIP = _os.environ.get("POPNET_ABLATE_SKIP", "")
 
 
@@ -110,6 +111,32 @@ class PoseEngine:
                                                                      C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.z.data_ptr()),
                                                                      _lib.current_stream_ptr(self.device)), "pn_rtpose_forward")
 
+    def _frames_args(self, depth):
+        _lib.require_cuda_tensor(depth, "depth")
+        if depth.dtype not in (torch.float16, torch.float32):
+            raise _lib.PopnetError("depth frames must be float16 or float32")
+        B, H, W = depth.shape
+        if B > self.max_batch:
+            raise _lib.PopnetError("batch %d exceeds max_batch %d" % (B, self.max_batch))
+        if not depth.is_contiguous():
+            raise _lib.PopnetError("depth frames must be contiguous")
+        dt = _lib.PN_DEPTH_F16 if depth.dtype == torch.float16 else _lib.PN_DEPTH_F32
+        return B, (C.c_void_p(depth.data_ptr()), dt, B, H, W, float(DEPTH_MAX), float(DEPTH_MEAN), float(DEPTH_STD))
+
+    def forward_frames(self, depth):
+        """preprocess + forward as ONE call on the raw frames (pn_rtpose_forward_frames: the stem resizes / clamps / normalises its own
+        input tile; bit-identical maps, the pre-processed tensor is never written).  The fp32 parity mode keeps the two calls."""
+        if _PREC.get(str(self.model.precision).lower()) == _lib.PN_PREC_F32 or _NO_FRAMES_IN:
+            B = self.preprocess(depth)
+            self.forward(B)
+            return B
+        B, args = self._frames_args(depth)
+        net = self.net
+        (self.model._ctx or self.ctx).check(self.L.pn_rtpose_forward_frames(net, *args, C.c_void_p(self.paf.data_ptr()), C.c_void_p(self.heat.data_ptr()),
+                                                                            C.c_void_p(self.z.data_ptr()), _lib.current_stream_ptr(self.device)),
+                                            "pn_rtpose_forward_frames")
+        return B
+
     def parse(self, B, frames=None, wire=None):
         """wire: optional device uint8 tensor [>= B, sizeof(pn_pose_wire)] that receives the compact records in the same launch."""
         frames = self.frames if frames is None else frames
@@ -123,8 +150,7 @@ class PoseEngine:
 
     def predict(self, depth, frames=None, wire=None):
         """depth [B,H,W] CUDA f16/f32 -> device uint8 tensor [B, sizeof(pn_pose_frame)] (no sync)."""
-        B = self.preprocess(depth)
-        self.forward(B)
+        B = self.forward_frames(depth)
         self.parse(B, frames, wire)
         return (self.frames if frames is None else frames)[:B]
 
@@ -203,6 +229,20 @@ class YoloEngine:
         (self.model._ctx or self.ctx).check(self.L.pn_yolo_forward(net, C.c_void_p(self.x.data_ptr()), B, C.c_void_p(self.out.data_ptr()),
                                                                    _lib.current_stream_ptr(self.device)), "pn_yolo_forward")
 
+    _frames_args = PoseEngine._frames_args
+
+    def forward_frames(self, depth):
+        """preprocess + forward as one call on the raw frames (pn_yolo_forward_frames); fp32 keeps the two calls."""
+        if _PREC.get(str(self.model.precision).lower()) == _lib.PN_PREC_F32 or _NO_FRAMES_IN:
+            B = self.preprocess(depth)
+            self.forward(B)
+            return B
+        B, args = self._frames_args(depth)
+        net = self.net
+        (self.model._ctx or self.ctx).check(self.L.pn_yolo_forward_frames(net, *args, C.c_void_p(self.out.data_ptr()), _lib.current_stream_ptr(self.device)),
+                                            "pn_yolo_forward_frames")
+        return B
+
     def parse(self, B, frames=None):
         frames = self.frames if frames is None else frames
         h = self.S // 16
@@ -214,8 +254,7 @@ class YoloEngine:
 
     def predict(self, depth, frames=None):
         """depth [B,H,W] CUDA f16/f32 -> device uint8 tensor [B, sizeof(pn_yolo_frame)] (no sync)."""
-        B = self.preprocess(depth)
-        self.forward(B)
+        B = self.forward_frames(depth)
         self.parse(B, frames)
         return (self.frames if frames is None else frames)[:B]
 

@@ -790,6 +790,42 @@ def test_engine_other_frame_sizes_and_dtypes(gpu, shape, dtype):
     assert compared >= 1
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("shape,dtype", [((640, 480), np.float16), ((240, 320), np.float32), ((512, 480), np.float16)])
+def test_frames_in_forward_equals_preprocess_plus_forward(gpu, prec, shape, dtype):
+    """pn_rtpose_forward_frames / pn_yolo_forward_frames (the stem computes its input tile from the raw frames with pn_preprocess's
+    arithmetic) give the SAME maps, bit for bit, as pn_preprocess + pn_*_forward, for f16 and f32 frames of three sizes; the fp32
+    parity net refuses the call (it keeps the two-call form)."""
+    import ctypes as C
+    from popnet_amd import _lib
+    from popnet_amd.pipeline import PoseEngine, YoloEngine
+    H, W = shape
+    depth = torch.from_numpy(synth.synth_depth(3, H, W, seed=37, dtype=dtype)).to(gpu)
+    eng = PoseEngine(precision=prec, device=gpu, max_batch=3, w_org=W, h_org=H)
+    B = eng.preprocess(depth)
+    eng.forward(B)
+    two = [t[:3].clone() for t in (eng.paf, eng.heat, eng.z)]
+    for t in (eng.paf, eng.heat, eng.z):
+        t.zero_()
+    assert eng.forward_frames(depth) == 3
+    torch.cuda.synchronize()
+    for a, b, name in zip(two, (eng.paf, eng.heat, eng.z), ("paf", "heat", "z")):
+        assert torch.isfinite(a).all() and torch.equal(a, b[:3]), name
+    if prec == "bf16":
+        ye = YoloEngine(precision=prec, device=gpu, max_batch=3, w_org=W, h_org=H)
+        B = ye.preprocess(depth)
+        ye.forward(B)
+        ref = ye.out[:3].clone()
+        ye.out.zero_()
+        ye.forward_frames(depth)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, ye.out[:3])
+        f32 = PoseEngine(precision="fp32", device=gpu, max_batch=3, w_org=W, h_org=H)
+        rc = _lib.lib().pn_rtpose_forward_frames(f32.net, C.c_void_p(depth.data_ptr()), _lib.PN_DEPTH_F16 if dtype == np.float16 else _lib.PN_DEPTH_F32, 3, H, W,
+                                                 6.0, 3.0, 2.0, C.c_void_p(f32.paf.data_ptr()), C.c_void_p(f32.heat.data_ptr()), C.c_void_p(f32.z.data_ptr()), None)
+        assert rc == -4                                 # PN_ERR_UNSUPPORTED (include/popnet_hip.h)
+
+
 @pytest.mark.parametrize("net", ["rtpose", "yolo"])
 def test_end_to_end_metrics_match_reference_script_and_metric_code(gpu, golden, tmp_path, net):
     """The closest thing to 'mAP / PCK identical on a test split' that can be shown without the dataset: 12 synthetic
