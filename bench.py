@@ -616,7 +616,7 @@ def main():
                            "what": "YoloPoseNet forward + box decode / NMS / skeleton read-out (SURVEY 8a rows 7, 12) through the same pipelined region (its own process)"}
         # RCCL on this box: one fresh rank under torch.distributed.run with the process group initialised on
         # backend "nccl" at world_size 1: the region's all-gather plus gather_records / the 22 MB gradient all-reduce on device tensors
-        rc = child_leg(["--force-dist", "--no-h2d", "--steps", "10", "--warmup", "3", "--reps", "1", "--pool", "2"])
+        rc = child_leg(["--force-dist", "--no-h2d", "--steps", "100", "--warmup", "5", "--reps", "2", "--pool", "2"])
         out["rccl_check"] = rc if "error" in rc else dict(rc.get("dist", {"error": "no dist block in the child's line"}), value_with_process_group=rc["value"])
         out["train_step"] = train_step_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0:

@@ -105,13 +105,19 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 4;
     const float *xb = x + (size_t)b * H * W;
     if (SRC != 0) {
+        // coordinate terms once per tile column / row (threads 0..37 / 64..101), then 4 taps + the interpolation per pixel
+        __shared__ PnAxisX axs[38];
+        __shared__ PnAxisY ays[38];
+        if (tid < 38) axs[tid] = pn_preproc_axis_x(ix0 + tid, src.scale_x, src.W);
+        else if (tid >= 64 && tid < 64 + 38) ays[tid - 64] = pn_preproc_axis_y(iy0 + tid - 64, src.scale_y, src.H);
+        __syncthreads();
         for (int i = tid; i < 38 * 38; i += 256) {
             const int r = i / 38, cc = i - r * 38;
             const int iy = iy0 + r, ix = ix0 + cc;
             float v = 0.f;
             if (r < 37 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                if (SRC == 1) v = pn_preproc_pixel((const _Float16 *)src.frames + (size_t)b * src.H * src.W, src.H, src.W, iy, ix, src.scale_x, src.scale_y, src.dmax, src.mean, src.stdv);
-                else v = pn_preproc_pixel((const float *)src.frames + (size_t)b * src.H * src.W, src.H, src.W, iy, ix, src.scale_x, src.scale_y, src.dmax, src.mean, src.stdv);
+                if (SRC == 1) v = pn_preproc_combine((const _Float16 *)src.frames + (size_t)b * src.H * src.W, src.W, axs[cc], ays[r], src.dmax, src.mean, src.stdv);
+                else v = pn_preproc_combine((const float *)src.frames + (size_t)b * src.H * src.W, src.W, axs[cc], ays[r], src.dmax, src.mean, src.stdv);
             }
             const __bf16 vh = (__bf16)v;
             tile[r * STEM_PITCH + cc] = vh;
