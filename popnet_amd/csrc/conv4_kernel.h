@@ -312,6 +312,10 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
                         // the end-of-kernel write-back of ~23 MB of dirty lines that the next launch has to wait for
                         pn_store16_wt(op, reinterpret_cast<u32x4 *>(ov)[0]);
                         pn_store16_wt(op + 1, reinterpret_cast<u32x4 *>(ov)[1]);
+#elif defined(PN4_NT_STORE)
+                        // experiment: non-temporal stores (conv3's v21, profiles/README.md: faster alone, slower in the network)
+                        __builtin_nontemporal_store(reinterpret_cast<u32x4 *>(ov)[0], op);
+                        __builtin_nontemporal_store(reinterpret_cast<u32x4 *>(ov)[1], op + 1);
 #else
                         op[0] = reinterpret_cast<u32x4 *>(ov)[0];
                         op[1] = reinterpret_cast<u32x4 *>(ov)[1];
