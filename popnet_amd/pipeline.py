@@ -118,8 +118,7 @@ class PoseEngine:
         B, H, W = depth.shape
         if B > self.max_batch:
             raise _lib.PopnetError("batch %d exceeds max_batch %d" % (B, self.max_batch))
-        if not depth.is_contiguous():
-            raise _lib.PopnetError("depth frames must be contiguous")
+        depth = depth.contiguous()                                   # (a copy, if one is made, is stream-ordered like every torch allocation)
         dt = _lib.PN_DEPTH_F16 if depth.dtype == torch.float16 else _lib.PN_DEPTH_F32
         return B, (C.c_void_p(depth.data_ptr()), dt, B, H, W, float(DEPTH_MAX), float(DEPTH_MEAN), float(DEPTH_STD))
 
