@@ -291,6 +291,14 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
                 cs.kern = 4;
         }
     }
+    // Small maps on the generic kernel (YoloPoseNet's 14 x 14 levels: 2 tiles per frame): 128-cout blocks give fewer blocks than the chip
+    // has CUs (128 at B = 32) -- 64-cout x 128-pixel blocks double them.  POPNET_GENERIC_C64=0 keeps the 128-cout blocks.
+    if (cs.kern == 0 && n->prec == PN_PREC_BF16 && cs.cfg == PN_CFG_C128 && cs.stride == 1) {
+        const Buf &ib1 = n->bufs[cs.in_buf];
+        const long blocks128 = (long)n->max_batch * ((ib1.H * ib1.W + 111) / 112) * (cout / 128);
+        const char *e = getenv("POPNET_GENERIC_C64");
+        if (blocks128 < n->ctx->num_cus && !(e && atoi(e) == 0)) cs.cfg = PN_CFG_C64;
+    }
     const int BC = cs.kern == 4 ? 128 : (cs.kern == 3 ? cs.wc * 32 : pn_cfg_couts(cs.cfg));
     const int cout_pad = (cout + BC - 1) / BC * BC;
     const int ctiles = cout_pad / 16;
