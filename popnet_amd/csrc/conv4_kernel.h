@@ -43,16 +43,17 @@
 #define PN4_BBUF (2 * PN4_BSTRIP)       // both strips
 #define PN4_LDS (PN4_ARING + 2 * PN4_BBUF)
 
-__global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__restrict__ probs) {
+// One block of problem P; block_x = the block's index within the problem's launch (blockIdx.x of conv4_kernel; the persistent
+// experiment of scripts/stagelab.hip walks several (problem, block_x) pairs per workgroup).
+__device__ __forceinline__ void conv4_body(const ConvProblem &P, const int block_x) {
     typedef __bf16 T;
     constexpr int KS = 3, KK = 9, PT = 7, CT = 4, PITCH = PN4_PITCH, RING = PN4_RING;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const ConvProblem &P = probs[blockIdx.y];
-    if ((int)blockIdx.x >= P.nblocks) return;
+    if (block_x >= P.nblocks) return;
     int bx;
     {   // XCD-aware remap, see conv_mfma_kernel.h
-        const int nb = P.nblocks, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int nb = P.nblocks, xcd = block_x & 7, idx = block_x >> 3;
         const int qq = nb >> 3, rr = nb & 7;
         bx = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
@@ -373,6 +374,10 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
         }
     }
     PN_STAMP_AT(12);
+}
+
+__global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__restrict__ probs) {
+    conv4_body(probs[blockIdx.y], (int)blockIdx.x);
 }
 
 static int conv4_launch(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
