@@ -210,6 +210,124 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem + MaxPool2d(3, 2, 1) in one launch (YoloPoseNet: conv1 - bn1 - relu - maxpool, resnet.py:134-148 / yolo_posenet.py:101-108;
+// net.hip::build_yolo, POPNET_NO_STEMPOOL=1 keeps the two launches).  A block owns 8 x 7 pooled pixels: it computes the 17 x 15
+// stem outputs their windows cover (one row and one column shared with the neighbouring blocks are recomputed), parks them as
+// bf16 in LDS and takes the window maxima there -- max is exact, so the result equals pool_kernel's on the stored map bit for
+// bit, and the 112 x 112 x 64 map (51 MB written and read back at B = 32) is never stored.  Same MFMA formulation as
+// stem7x7_mfma_kernel (20 output rows per block instead of 16: wave w owns rows 5w .. 5w + 4, rows 17..19 are skipped).
+// ---------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void stem7x7_pool_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wfrag,
+                                                            const float *__restrict__ bias, __bf16 *__restrict__ out,
+                                                            int H, int W, int Ho, int Wo, int Hp, int Wp, int out_cs, PnFrameSrc src) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[40 * STEM_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 otile[17 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z, py0 = blockIdx.y * 8, px0 = blockIdx.x * 7;
+    const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;                  // first stem output row / column of the block (may be -1)
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 4;
+    if (SRC != 0) {
+        __shared__ PnAxisX axs[38];
+        __shared__ PnAxisY ays[40];
+        if (tid < 38) axs[tid] = pn_preproc_axis_x(ix0 + tid, src.scale_x, src.W);
+        else if (tid >= 64 && tid < 64 + 40) ays[tid - 64] = pn_preproc_axis_y(iy0 + tid - 64, src.scale_y, src.H);
+        __syncthreads();
+        for (int i = tid; i < 40 * 38; i += 256) {
+            const int r = i / 38, cc = i - r * 38;
+            const int iy = iy0 + r, ix = ix0 + cc;
+            float v = 0.f;
+            if (r < 39 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                if (SRC == 1) v = pn_preproc_combine((const _Float16 *)src.frames + (size_t)b * src.H * src.W, src.W, axs[cc], ays[r], src.dmax, src.mean, src.stdv);
+                else v = pn_preproc_combine((const float *)src.frames + (size_t)b * src.H * src.W, src.W, axs[cc], ays[r], src.dmax, src.mean, src.stdv);
+            }
+            tile[r * STEM_PITCH + cc] = (__bf16)v;
+        }
+    } else {
+        const float *xb = x + (size_t)b * H * W;
+        for (int i = tid; i < 40 * 38; i += 256) {
+            const int r = i / 38, cc = i - r * 38;
+            const int iy = iy0 + r, ix = ix0 + cc;
+            float v = 0.f;
+            if (r < 39 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[(size_t)iy * W + ix];
+            tile[r * STEM_PITCH + cc] = (__bf16)v;             // row 39 (tap row 7 of output row 16) is zero: its weights are zero
+        }
+    }
+    stem_bf16x8 aw[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) aw[t][s2] = *reinterpret_cast<const stem_bf16x8 *>(wfrag + ((t * 2 + s2) * 64 + lane) * 8);
+    float bs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bs[i] = bias[16 * q + i];
+    __syncthreads();
+    for (int rr = 0; rr < 5; ++rr) {
+        const int ry = wave * 5 + rr;                           // wave-uniform
+        if (ry >= 17) break;
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned *sp = reinterpret_cast<const unsigned *>(&tile[(2 * ry + 4 * s2 + q) * STEM_PITCH + 2 * c]);
+            stem_u32x4 raw = {sp[0], sp[1], sp[2], sp[3]};
+            stem_bf16x8 bf = *reinterpret_cast<stem_bf16x8 *>(&raw);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t][s2], bf, acc[t], 0, 0, 0);
+        }
+        __bf16 o[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][r] + bs[4 * t + r];
+                o[4 * t + r] = (__bf16)(v > 0.f ? v : 0.f);       // the same bias + ReLU + rounding as stem7x7_mfma_kernel's epilogue
+            }
+        stem_u32x4 *dst = reinterpret_cast<stem_u32x4 *>(&otile[(ry * 16 + c) * 64 + 16 * q]);
+        dst[0] = reinterpret_cast<stem_u32x4 *>(o)[0];
+        dst[1] = reinterpret_cast<stem_u32x4 *>(o)[1];
+    }
+    __syncthreads();
+    for (int item = tid; item < 8 * 7 * 8; item += 256) {
+        const int g8 = item & 7, pp = item >> 3, pi = pp / 7, pj = pp - pi * 7;
+        const int py = py0 + pi, px = px0 + pj;
+        if (py >= Hp || px >= Wp) continue;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ry = 2 * pi + ky, cc = 2 * pj + kx;     // window taps in block coordinates; map coordinates oy0 + ry, ox0 + cc
+                const bool ok = (unsigned)(oy0 + ry) < (unsigned)Ho && (unsigned)(ox0 + cc) < (unsigned)Wo;
+                __bf16 tv[8];
+                *reinterpret_cast<stem_u32x4 *>(tv) = *reinterpret_cast<const stem_u32x4 *>(&otile[(ry * 16 + cc) * 64 + g8 * 8]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = ok ? fmaxf(m[k], (float)tv[k]) : m[k];
+            }
+        __bf16 o8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o8[k] = (__bf16)m[k];
+        *reinterpret_cast<stem_u32x4 *>(out + ((size_t)(b * Hp + py) * Wp + px) * out_cs + g8 * 8) = *reinterpret_cast<stem_u32x4 *>(o8);
+    }
+}
+
+int pn_launch_stem_pool(pn_ctx *ctx, const float *x, const void *wfrag, const float *bias, void *out, int B, int H, int W, int Ho, int Wo,
+                        int out_cs, hipStream_t stream, const PnFrameSrc *src) {
+    const int Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1;
+    dim3 grid((Wp + 6) / 7, (Hp + 7) / 8, B), block(256);
+    const PnFrameSrc none = {};
+    if (!src) hipLaunchKernelGGL(stem7x7_pool_kernel<0>, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, Hp, Wp, out_cs, none);
+    else if (src->dtype == PN_DEPTH_F16) hipLaunchKernelGGL(stem7x7_pool_kernel<1>, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, Hp, Wp, out_cs, *src);
+    else hipLaunchKernelGGL(stem7x7_pool_kernel<2>, grid, block, 0, stream, x, (const __bf16 *)wfrag, bias, (__bf16 *)out, H, W, Ho, Wo, Hp, Wp, out_cs, *src);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
 int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const void *wfrag, const float *bias, void *out,
                    int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream, const PnFrameSrc *src) {
     dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B), block(256);

@@ -71,6 +71,7 @@ struct Step {
     float *bb_bias1 = nullptr, *bb_bias2 = nullptr;
     // STEM
     int out_buf = -1;
+    int stem_pool_buf = -1;          // >= 0: the MaxPool2d(3, 2, 1) that follows runs inside the stem launch and writes this buffer (build_yolo)
     float *stem_w = nullptr, *stem_b = nullptr;
     void *stem_wfrag = nullptr;      // bf16 MFMA fragments of the same weights
     // POOL
@@ -820,7 +821,10 @@ int build_yolo(pn_net *n) {
     if (int rc = add_stem(n, A1)) return rc;
     std::vector<std::vector<int>> levels;
     auto level = [&](std::vector<int> ids) { levels.push_back(ids); };
-    levels.push_back({-1, 1, A1, X0, 64, 0});   // maxpool 3x3 s2
+    // conv1 - bn1 - relu - maxpool (yolo_posenet.py:101-108): one launch in bf16 (conv_misc.hip::stem7x7_pool_kernel; the 112 x 112 x 64
+    // map is never stored); POPNET_NO_STEMPOOL=1, fp32 and bf16x3 keep the stem and the pool as two launches
+    if (n->prec == PN_PREC_BF16 && !n->x3 && !getenv("POPNET_NO_STEMPOOL")) n->steps.back().stem_pool_buf = X0;
+    else levels.push_back({-1, 1, A1, X0, 64, 0});   // maxpool 3x3 s2
     int cur = X0, other = X1;
     for (int i = 0; i < 3; ++i) {
         std::string p = "model0.layer1." + std::to_string(i);
@@ -1002,7 +1006,10 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
                               (st.launch.kern == 4 ? "conv4" : st.launch.kern == 3 ? (st.launch.ks == 1 ? "c1x1" : "c3") : "head");
             if (strstr(skip, cls)) { if (pr) PN_HIP_CHECK(ctx, hipEventRecord(pr->b, stream)); continue; }
         }
-        if (st.type == Step::STEM) {
+        if (st.type == Step::STEM && st.stem_pool_buf >= 0) {
+            const Buf &ob = n->bufs[st.out_buf], &pb = n->bufs[st.stem_pool_buf];
+            rc = pn_launch_stem_pool(ctx, x, st.stem_wfrag, st.stem_b, pb.p, B, n->in_h, n->in_w, ob.H, ob.W, pb.C, stream, n->frame_src.frames ? &n->frame_src : nullptr);
+        } else if (st.type == Step::STEM) {
             const Buf &ob = n->bufs[st.out_buf];
             rc = pn_launch_stem(ctx, n->x3 ? PN_PREC_BF16X3 : n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, n->x3 ? ob.plane : 0, stream,
                                 n->frame_src.frames ? &n->frame_src : nullptr);

@@ -149,6 +149,10 @@ int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 
 // stem: 7x7 stride-2 pad-3, Cin = 1, fused folded-BN bias + ReLU.  x NCHW f32 [B,1,H,W] ->
 // NHWC T [B,Ho,Wo,64].  w [49][64] f32 (tap-major) for the fp32 VALU kernel, wfrag = the same weights as
 // 8 bf16 MFMA A-fragments (see stem7x7_mfma_kernel) for bf16 mode, bias [64].
+struct PnFrameSrc;
+// stem + MaxPool2d(3, 2, 1) in one launch (bf16 nets; conv_misc.hip): out = the POOLED map [B, (Ho-1)/2+1, (Wo-1)/2+1, out_cs]
+int pn_launch_stem_pool(pn_ctx *ctx, const float *x, const void *wfrag, const float *bias, void *out, int B, int H, int W, int Ho, int Wo,
+                        int out_cs, hipStream_t stream, const PnFrameSrc *src);
 struct PnFrameSrc;       // preproc_pixel.h: raw depth frames + the pre-processing constants (nullptr = x is the pre-processed input)
 int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const void *wfrag, const float *bias,
                    void *out, int B, int H, int W, int Ho, int Wo, int out_cs, int split, hipStream_t stream, const PnFrameSrc *src = nullptr);

@@ -175,7 +175,7 @@ def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, mo
         assert torch.equal(got4_y, ref_y)
 
 
-@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0", "POPNET_NO_BBLOCK=1", "POPNET_NO_TAILFUSE=1", "POPNET_NO_MIX=1", "POPNET_NO_POOLFUSE=1", "POPNET_GENERIC_C64=0"])
+@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0", "POPNET_NO_BBLOCK=1", "POPNET_NO_TAILFUSE=1", "POPNET_NO_MIX=1", "POPNET_NO_POOLFUSE=1", "POPNET_GENERIC_C64=0", "POPNET_NO_STEMPOOL=1"])
 def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, monkeypatch):
     """The experiment switches of profiles/README.md (224-pixel wave tiles, double-buffered halo images, 8-row tiles on
     14-column maps; conv4_kernel on every / no level; the two layer1 BasicBlocks as two launches each instead of the fused
@@ -201,6 +201,29 @@ def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, mo
     for a, b, name in zip(got, ref, ("paf", "heat", "z")):
         assert torch.isfinite(a).all() and torch.equal(a, b), (switch, name)
     assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y), switch
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (256, 192), (96, 480), (240, 336)])
+def test_yolo_stem_with_fused_maxpool_is_bit_identical(gpu, golden, hw, monkeypatch):
+    """YoloPoseNet's conv1 - bn1 - relu - maxpool as one launch (stem7x7_pool_kernel: 8 x 7 pooled pixels per block, the window maxima
+    taken in LDS) against the stem and the pool as two launches (POPNET_NO_STEMPOOL=1), at sizes whose pooled maps are not multiples of
+    the block tile: same output tensor, bit for bit."""
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    H, W = hw
+    x = torch.from_numpy(np.random.default_rng(26).normal(0, 1, (3, 1, H, W)).astype(np.float32)).to(gpu)
+
+    def yolo():
+        m = YoloPoseNet(15, input_dim=1).eval()
+        m.load_state_dict(state_dict_from_keys(golden.keys["yolo_posenet"], seed=1))
+        m.precision = "bf16"
+        return m
+
+    got = yolo()(x).clone()
+    monkeypatch.setenv("POPNET_NO_STEMPOOL", "1")          # read when the net is compiled
+    ref = yolo()(x).clone()
+    monkeypatch.delenv("POPNET_NO_STEMPOOL")
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and torch.equal(got, ref)
 
 
 def test_bf16_batch_invariance_and_ragged_batches(gpu, golden):
