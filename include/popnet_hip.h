@@ -56,6 +56,10 @@ typedef struct pn_net pn_net;
 /* ---- context -------------------------------------------------------------------------------
  * One context per GPU / stream owner.  Not thread-safe per context; independent contexts are. */
 int pn_abi_version(void);
+/* 1 when the library was built with -DPN_EXPERIMENTS (lab builds: the timing-only ablation and mixed-precision environment
+ * switches POPNET_ABLATE_SKIP / POPNET_X3_BF16_CONVS are compiled in and can change results), 0 for the shipped library, which
+ * honours no result-changing environment variable.  bench.py refuses to time a lab build. */
+int pn_build_experiments(void);
 pn_ctx *pn_create(int device_id);
 void pn_destroy(pn_ctx *ctx);
 /* Copies the last error message of this context into buf (NUL-terminated). Returns its length. */

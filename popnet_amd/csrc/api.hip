@@ -34,6 +34,13 @@ __global__ void preprocess_kernel(const TIN *__restrict__ depth, float *__restri
 extern "C" {
 
 int pn_abi_version(void) { return PN_ABI_VERSION; }
+int pn_build_experiments(void) {
+#ifdef PN_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 pn_ctx *pn_create(int device_id) {
     pn_ctx *ctx = new pn_ctx();

@@ -140,8 +140,11 @@ struct BBProblem {
     int in_cs, in_coff, out_cs, out_coff;
     int Wt, tiles_x, tiles_per_img, ntiles;
     unsigned in_zero_off;  // byte offset from `in` to >= 16 zero bytes
+    // bb64x3_kernel (bf16x3 nets): plane distance in channels of the three-plane [hi | lo | hi] input / output tensors; wpack = 72 x 4 KB
+    int in_split, out_split;
 };
 int pn_launch_bb64(pn_ctx *ctx, const BBProblem &P, hipStream_t stream);       // bb64_inst.hip
+int pn_launch_bb64x3(pn_ctx *ctx, const BBProblem &P, hipStream_t stream);     // bb64x3_inst.hip (6-row tiles: tiles_per_img = ceil(H / 6) * tiles_x)
 size_t pn_conv3_lds_bytes(int ks, int WP, int nbuf, int rpg = 4);
 size_t pn_conv_lds_bytes(int prec, int ks, int stride, int pitch, int R);
 int pn_conv_stage_maxpx(int prec, int ks, int stride, int pitch, int cfg);   // 0 = no limit (direct staging)

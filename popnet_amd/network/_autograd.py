@@ -126,7 +126,12 @@ class AvgPool3s2Fn(torch.autograd.Function):
 
 
 def conv(x, m):
-    """nn.Conv2d parameter holder `m` applied through Conv2dFn."""
+    """nn.Conv2d parameter holder `m` applied through Conv2dFn.  The HIP primitive is the reference's convolution -- square stride and
+    zero padding, no dilation, no groups (rtpose_light3d.py:24-34, 222-246) -- anything else is refused rather than silently ignored."""
+    if (tuple(m.dilation) != (1, 1) or m.groups != 1 or m.stride[0] != m.stride[1] or isinstance(m.padding, str)
+            or m.padding[0] != m.padding[1] or m.padding_mode != "zeros"):
+        raise _lib.PopnetError("popnet_amd: Conv2d(dilation=%s, groups=%s, stride=%s, padding=%s, padding_mode=%r) is outside what pn_conv2d_forward "
+                               "computes (square stride / zero padding, no dilation, no groups)" % (m.dilation, m.groups, m.stride, m.padding, m.padding_mode))
     return Conv2dFn.apply(x, m.weight, m.bias, m.stride[0], m.padding[0])
 
 
@@ -134,7 +139,10 @@ def bn_act(x, m, act, res=None):
     """nn.BatchNorm2d parameter holder `m` in train mode (+ residual, + activation); counts the batch like torch does."""
     if m.num_batches_tracked is not None:
         m.num_batches_tracked.add_(1)
-    momentum = 0.1 if m.momentum is None else m.momentum
+    if m.momentum is None:          # torch: cumulative moving average, factor 1 / num_batches_tracked (nn.modules.batchnorm._BatchNorm.forward)
+        momentum = 1.0 / float(m.num_batches_tracked) if m.num_batches_tracked is not None else 0.0
+    else:
+        momentum = m.momentum
     return BatchNormActFn.apply(x, m.weight, m.bias, res, m.running_mean, m.running_var, act, momentum, m.eps)
 
 

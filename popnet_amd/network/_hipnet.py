@@ -31,6 +31,8 @@ class HipNetModule(nn.Module):
         self.precision = default_precision()
         self._net = None          # (handle, key)
         self._ctx = None
+        self._pins = {}           # pn_net handle -> number of engines that hold it locked (a captured hipGraph refers to it)
+        self._retired = []        # pinned handles this module no longer uses: destroyed when their last pin goes
 
     # ---- compilation ----------------------------------------------------------------------
     def _net_args(self):
@@ -40,12 +42,36 @@ class HipNetModule(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _release(self):
+        """Drops the compiled net.  A handle an engine holds locked (PoseEngine.lock / StreamingEngine.capture: captured hipGraphs
+        point at its device buffers and launch descriptors) is NOT destroyed here -- it is retired and freed by the unlock, so a
+        recompile under a captured engine can never turn a graph replay into a use-after-free."""
         if self._net is not None:
-            _lib.lib().pn_net_destroy(self._net[0])
+            h = self._net[0]
+            if self._pins.get(h, 0) > 0:
+                self._retired.append(h)
+            else:
+                _lib.lib().pn_net_destroy(h)
             self._net = None
+
+    def _pin(self, handle):
+        self._pins[handle] = self._pins.get(handle, 0) + 1
+
+    def _unpin(self, handle):
+        n = self._pins.get(handle, 0) - 1
+        if n > 0:
+            self._pins[handle] = n
+            return
+        self._pins.pop(handle, None)
+        if handle in self._retired:
+            self._retired.remove(handle)
+            _lib.lib().pn_net_destroy(handle)
 
     def __del__(self):
         try:
+            self._pins = {}
+            for h in self._retired:
+                _lib.lib().pn_net_destroy(h)
+            self._retired = []
             self._release()
         except Exception:
             pass

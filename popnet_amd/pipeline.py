@@ -25,7 +25,6 @@ from .utils.paf_to_pose import make_parse_cfg
 
 import os as _os
 _NO_FRAMES_IN = bool(_os.environ.get("POPNET_NO_FRAMES_IN"))     # experiment switch: pn_preprocess + pn_*_forward as two calls in every precision
-_ABLATE_SKIP = _os.environ.get("POPNET_ABLATE_SKIP", "")
 
 
 class PoseEngine:
@@ -57,6 +56,7 @@ class PoseEngine:
         if self.private_ctx:
             self.ctx.check(self.L.pn_parse_reserve(self.ctx.handle, self.max_batch), "pn_parse_reserve")
         self._locked = False
+        self._locked_net = None
         h = self.S // 8
         d, f32 = self.device, torch.float32
         self.x = torch.empty((self.max_batch, 1, self.S, self.S), device=d, dtype=f32)
@@ -72,20 +72,36 @@ class PoseEngine:
         forward at another size or precision, so the engine never keeps a raw copy: it re-reads (or re-compiles) here."""
         # always through _compile: it compares the FULL key (device, precision, input size, weights version), so a net the
         # module compiled for another size / precision by a direct model(x) call is never run on this engine's buffers
-        before = self.model._net[0] if self.model._net is not None else None
-        if self._locked and before is not None:
+        if self._locked:
+            # a captured hipGraph refers to the pn_net this engine was locked on.  invalidate() / load_state_dict() / a train-mode
+            # forward release the module's handle (the locked one is only retired, never freed: HipNetModule._release): refuse to
+            # run -- and above all to silently compile a fresh net next to graphs that still replay the old one
+            cur = self.model._net
             prec = _PREC.get(str(self.model.precision).lower())
             key = (self.device.index, prec, self.S, self.S, self.model._weights_version())
-            if self.model._net[1] != key or self.model._net[2] < self.max_batch:
-                raise _lib.PopnetError("PoseEngine: the module was recompiled or modified while the engine is locked / captured "
-                                       "(a captured hipGraph still refers to the old pn_net)")
+            if cur is None or cur[0] != self._locked_net or cur[1] != key or cur[2] < self.max_batch:
+                raise _lib.PopnetError("PoseEngine: the module was invalidated, recompiled or modified while the engine is locked / captured "
+                                       "(a captured hipGraph still refers to the pn_net of the lock): unlock -- lock(False) -- and capture again")
+            return cur[0]
         return self.model._compile(self.device, self.max_batch, self.S, self.S)
 
     def lock(self, locked=True):
-        """Freeze the net's launch descriptors (call after a warm-up forward, before capturing a hipGraph)."""
-        net = self.net
-        (self.model._ctx or self.ctx).check(self.L.pn_net_lock(net, 1 if locked else 0), "pn_net_lock")
-        self._locked = bool(locked)
+        """Freeze the net's launch descriptors (call after a warm-up forward, before capturing a hipGraph).  The locked handle
+        is pinned in the module: nothing destroys it until lock(False)."""
+        if locked:
+            if self._locked:
+                return
+            net = self.net
+            (self.model._ctx or self.ctx).check(self.L.pn_net_lock(net, 1), "pn_net_lock")
+            self.model._pin(net)
+            self._locked_net = net
+            self._locked = True
+        elif self._locked:
+            net = self._locked_net
+            self._locked = False
+            self._locked_net = None
+            (self.model._ctx or self.ctx).check(self.L.pn_net_lock(net, 0), "pn_net_lock")
+            self.model._unpin(net)                                   # frees the handle if the module had retired it meanwhile
 
     # ---- stages (all asynchronous on the current stream) --------------------------------------
     def preprocess(self, depth):
@@ -140,8 +156,6 @@ class PoseEngine:
         """wire: optional device uint8 tensor [>= B, sizeof(pn_pose_wire)] that receives the compact records in the same launch."""
         frames = self.frames if frames is None else frames
         h = self.S // 8
-        if "parse" in _ABLATE_SKIP:              # timing-only ablation (scripts/experiments/tail_ablation.sh): wrong results
-            return
         self.ctx.check(self.L.pn_parse_paf_wire(self.ctx.handle, C.c_void_p(self.heat.data_ptr()), C.c_void_p(self.paf.data_ptr()),
                                                 C.c_void_p(self.z.data_ptr()), B, h, h, C.byref(self.cfg), C.c_void_p(frames.data_ptr()),
                                                 C.c_void_p(wire.data_ptr() if wire is not None else None),
@@ -217,6 +231,7 @@ class YoloEngine:
                                dtype=torch.float32)
         self.frames = torch.empty((self.max_batch, _lib.YOLO_FRAME_DTYPE.itemsize), device=d, dtype=torch.uint8)
         self._locked = False
+        self._locked_net = None
         self.flops_per_frame = self.L.pn_net_flops_per_frame(self.net)
 
     preprocess = PoseEngine.preprocess

@@ -79,10 +79,14 @@ def _sweep_worker(rank, world, root_dir, n_frames, port, ret):
     dist.destroy_process_group()
 
 
-def test_sharded_dataset_sweep_world2_gloo(tmp_path):
-    """dataset.run_sweep with two ranks: every rank ends up with all records in label-file order (ragged last batches)."""
+import pytest
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 11), (8, 45)])
+def test_sharded_dataset_sweep_world2_gloo(tmp_path, world, n_frames):
+    """dataset.run_sweep (what scripts/evaluate_mpreal.py drives) with two and with EIGHT ranks -- the node size of BASELINE configs[2]:
+    every rank ends up with all records in label-file order (ragged last batches, shards of unequal length)."""
     import json
-    n_frames = 11
     labels = {"intrinsics": {"fx": 1, "fy": 1, "cx": 0, "cy": 0}}
     for i in range(n_frames):
         name = "z%02d.npy" % (n_frames - i)                      # names NOT in sorted order: dict order must win
@@ -92,8 +96,8 @@ def test_sharded_dataset_sweep_world2_gloo(tmp_path):
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29700 + (os.getpid() % 1000)
-    mp.spawn(_sweep_worker, args=(2, str(tmp_path), n_frames, port, ret), nprocs=2, join=True)
-    assert ret[0] and ret[1]
+    mp.spawn(_sweep_worker, args=(world, str(tmp_path), n_frames, port + world, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)) and len(ret) == world
 
 
 def test_bench_self_launches_ranks_from_a_bare_shell():
@@ -147,3 +151,45 @@ def test_training_gradient_exchange_world2_gloo():
     ret = mgr.dict()
     mp.spawn(_train_dp_worker, args=(2, 29500 + (os.getpid() % 1000) + 11, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_bench_world8_dry_run_and_rank0_only_legs():
+    """Readiness for the driver's 8-GPU SCALE pass, on the CPU: `bench.py --gpus 8` from a bare shell starts eight
+    ranks, every rank enters the collectives of dist_check (the record all-gather and the 22 MB gradient all-reduce, gloo here, RCCL
+    there), rank 0 prints ONE line; and the plan of secondary legs is empty for every rank of a multi-rank run -- no child process, CPU
+    baseline or extra engine next to the other ranks."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--launcher-dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["launcher_dry_run"] and out["n_gpus"] == 8 and out["rank_sum"] == 36
+    assert out["dist"]["world_size"] == 8 and out["dist"]["gather_records_ok"] and out["dist"]["flat_gradient_allreduce_ok"], out["dist"]
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (2, 4, 8):
+        for rank in range(world):
+            assert not any(bench.plan_legs(world, rank, "rtpose", "bf16", False, False).values()), (world, rank)
+    solo = bench.plan_legs(1, 0, "rtpose", "bf16", False, False)
+    assert all(solo.values())
+    assert not bench.plan_legs(1, 0, "rtpose", "bf16", True, True)["children"]         # --no-extras (what the child legs themselves run with)
+
+
+def test_bench_refuses_ablation_switches():
+    """A timed region must not be one environment variable away from skipping launches: bench.py exits before
+    anything runs when a timing-only / result-changing experiment switch is set, and the shipped library has them compiled out."""
+    import subprocess
+    for var in ("POPNET_ABLATE_SKIP", "POPNET_X3_BF16_CONVS"):
+        env = dict(os.environ, **{var: "pool"})
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-dry-run"], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "refusing to run" in (r.stderr + r.stdout), (var, r.stderr[-500:])
+    import popnet_amd  # noqa: F401
+    from popnet_amd import _lib
+    assert _lib.lib().pn_build_experiments() == 0
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"POPNET_ABLATE_SKIP" not in blob and b"POPNET_X3_BF16_CONVS" not in blob

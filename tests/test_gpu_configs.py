@@ -86,3 +86,45 @@ def test_config3_multi_person_batches_match_the_oracle(gpu, persons):
             assert np.array_equal(recs[b]["joints_3d"][:n], np.array(ref["humans_3d"]))
             assert int(wrec[b]["n_persons"]) == n and np.array_equal(wrec[b]["person_joint"][:min(n, 16)], recs[b]["person_joint"][:min(n, 16)].astype(np.int16))
     assert found >= 32 * persons * 0.9          # the planted skeletons are (nearly) all assembled
+
+
+def test_locked_engine_survives_an_invalidated_module(gpu):
+    """invalidate() / load_state_dict() on the module of a LOCKED engine (its hipGraphs point at the pn_net's device
+    buffers and descriptors).  The locked handle must not be destroyed (it is retired: a replay stays memory-safe and reproduces
+    the records of the weights it was captured with), the engine must refuse to run -- and not silently compile a second net --
+    until it is unlocked, and the unlock frees the retired handle and lets the engine recompile."""
+    from popnet_amd import _lib, synth
+    from popnet_amd.pipeline import PoseEngine
+    eng = PoseEngine(precision="bf16", device=gpu, max_batch=4)
+    d = torch.from_numpy(synth.synth_depth(4, seed=3)).to(gpu)
+    out = torch.zeros((4, _lib.POSE_FRAME_DTYPE.itemsize), device=gpu, dtype=torch.uint8)
+    eng.predict(d, out)
+    torch.cuda.synchronize()
+    want = out.clone()
+    eng.lock()
+    handle = eng._locked_net
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        eng.predict(d, out)
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        eng.predict(d, out)
+    eng.model.invalidate()                                        # what load_state_dict() and a train-mode forward do as well
+    assert eng.model._net is None and eng.model._retired == [handle] and eng.model._pins == {handle: 1}
+    with pytest.raises(_lib.PopnetError, match="locked / captured"):
+        eng.predict(d, out)
+    assert eng.model._net is None                                 # ... and no fresh net was compiled behind the graph's back
+    out.zero_()
+    g.replay()                                                    # the retired net is still alive: same records as before
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    del g
+    eng.lock(False)
+    assert eng.model._retired == [] and eng.model._pins == {}
+    out.zero_()
+    eng.predict(d, out)                                           # unlocked: recompiles and runs
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)

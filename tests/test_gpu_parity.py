@@ -203,6 +203,40 @@ def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, mo
     assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y), switch
 
 
+@pytest.mark.parametrize("hw,B", [((224, 224), 5), ((200, 232), 3), ((256, 192), 2), ((96, 480), 3), ((72, 136), 4)])
+def test_bf16x3_fused_basic_block_equals_the_two_launch_plan_bit_for_bit(gpu, golden, hw, B, monkeypatch):
+    """bb64x3_kernel: the BasicBlock(64)s of the split-bf16 nets as ONE launch -- two-plane LDS images, the
+    intermediate map never leaves the CU -- against the two conv3_kernel launches per block (POPNET_NO_BBLOCK=1) under
+    precision="bf16x3": same k order (plane pair, half, tap), same MFMA, same epilogue arithmetic, so the maps must be IDENTICAL.
+    Sizes: the bench's 112 x 112 maps (6-row tiles: 18 full + one 4-row tile), ragged widths (100 x 116 -> 25 / 29-column strips,
+    128 x 96 -> 24-column strips, 48 x 240), a 36 x 68 map (six full row tiles, 23 / 22-column strips); rtpose's layer1 (two blocks at
+    H / 2) and YoloPoseNet's (three blocks at H / 4)."""
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    H, W = hw
+    x = torch.from_numpy(np.random.default_rng(36).normal(0, 1, (B, 1, H, W)).astype(np.float32)).to(gpu)
+
+    def yolo():
+        m = YoloPoseNet(15, input_dim=1).eval()
+        m.load_state_dict(state_dict_from_keys(golden.keys["yolo_posenet"], seed=1))
+        m.precision = "bf16x3"
+        return m
+
+    do_yolo = H % 16 == 0 and W % 16 == 0
+    got = [t.clone() for t in _rtpose(golden, "bf16x3")(x)[0]]
+    got_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.setenv("POPNET_NO_BBLOCK", "1")          # read when the net is compiled
+    ref = [t.clone() for t in _rtpose(golden, "bf16x3")(x)[0]]
+    ref_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.delenv("POPNET_NO_BBLOCK")
+    f32 = [t.clone() for t in _rtpose(golden, "fp32")(x)[0]]
+    torch.cuda.synchronize()
+    for a, b, c, name in zip(got, ref, f32, ("paf", "heat", "z")):
+        assert torch.isfinite(a).all() and torch.equal(a, b), name
+        assert float((a - c).abs().max()) < 5e-4, name            # and the bf16x3 maps stay fp32-class
+    if do_yolo:
+        assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y)
+
+
 @pytest.mark.parametrize("hw", [(224, 224), (256, 192), (96, 480), (240, 336)])
 def test_yolo_stem_with_fused_maxpool_is_bit_identical(gpu, golden, hw, monkeypatch):
     """YoloPoseNet's conv1 - bn1 - relu - maxpool as one launch (stem7x7_pool_kernel: 8 x 7 pooled pixels per block, the window maxima
