@@ -3,7 +3,7 @@
 // replaces the two conv3_kernel<3, 2, 2, 1, 7, 4> launches per block of tpm/lib/network/rtpose_light3d.py:48-72 (BasicBlock.forward) for
 // model0.layer1 (rtpose_light3d.py:145-152) and resnet.BasicBlock (tpm/lib/network/resnet.py:27-56) for YoloPoseNet's layer1.
 //
-// bf16x3 (net.hip::prepare_conv): a tensor is three bf16 planes [hi | lo | hi], weights are [W_hi | W_hi | W_lo] along Cin, one
+// bf16x3 (net.hip::prepare_conv): a tensor is two bf16 planes [hi | lo] read as [hi | lo | hi], weights are [W_hi | W_hi | W_lo] along Cin, one
 // bf16 MFMA convolution over 3 x 64 channels computes x_hi W_hi + x_lo W_hi + x_hi W_lo in fp32 accumulators.  Unfused, a BasicBlock moves a
 // 154 MB three-plane tensor through HBM four times (4 x 127.5 us per step at 0.28 of the physical peak).  The third plane
 // is a copy of the first, so the LDS images of the fused kernel hold TWO planes and the K loop addresses the hi image twice:
@@ -40,6 +40,8 @@
 #define BX_KS 54                              // k-steps per convolution: 3 plane pairs x 2 halves x 9 taps
 #ifdef BX_FAKE_NOBAR                          // timing-only ablation (scripts/bbx3lab.hip): no per-k-step barrier
 #define BX_KBAR do {} while (0)
+#elif defined(BX_LAGA)                        // the slot of step g is refilled during step g: its fragment reads (issued in the first MFMA groups of step g - 1) are drained first
+#define BX_KBAR asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory")
 #else
 #define BX_KBAR asm volatile("s_barrier" ::: "memory")
 #endif
@@ -84,7 +86,12 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
                 sn = sn == BX_NSLOT - 1 ? 0 : sn + 1;
             };
             dma_next(); dma_next(); dma_next(); dma_next();     // k-steps 0..3
+#ifdef BX_LAGA
+            dma_next();                                          // ... and 4: the loop issues step g + 5 into the slot of step g (three steps of slack)
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");        // 0 and 1 have landed
+#endif
             asm volatile("s_barrier" ::: "memory");              // (the compute waves have read k-step 0's fragments)
             for (; t < P.ntiles; t += gridDim.x) {
 #pragma clang loop unroll(disable)
@@ -96,6 +103,8 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
                     BX_KBAR;
 #elif defined(BX_FAKE_NOBAR)
                     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#elif defined(BX_LAGA)
+                    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");  // g + 2 has landed; g + 3 .. g + 5 in flight
 #else
                     asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // g + 2 has landed
 #endif
@@ -200,10 +209,17 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
                 const int j = ph * PT1 + pt, jr = j + BQ - 1;
                 // the next step's four A fragments in the first two MFMA groups: the last one is >= 10 MFMAs old when its first MFMA issues
 #ifndef BX_FAKE_NOA
+#ifdef BX_A_G0
+                if (pt == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) aq[(ph + 1) & 1][ct] = *reinterpret_cast<const bf16x8 *>(smem + an + ct * 1024);
+                }
+#else
                 if (pt < 2) {
                     aq[(ph + 1) & 1][2 * pt] = *reinterpret_cast<const bf16x8 *>(smem + an + (2 * pt) * 1024);
                     aq[(ph + 1) & 1][2 * pt + 1] = *reinterpret_cast<const bf16x8 *>(smem + an + (2 * pt + 1) * 1024);
                 }
+#endif
 #endif
 #ifndef BX_FAKE_NOB
                 if (jr < BX_KS * PT1) bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + ba1[jr % PT1] + BX_OFF1(jr));
@@ -211,9 +227,15 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ph & 1][ct], bq[j % BQ], acc[ct][pt], 0, 0, 0);
+#ifdef BX_A_G0
+                if (pt == 0 && jr < BX_KS * PT1) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                else if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                else if (jr < BX_KS * PT1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#else
                 if (pt < 2 && jr < BX_KS * PT1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 else if (pt < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 else if (jr < BX_KS * PT1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -276,10 +298,17 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
             for (int pt = 0; pt < PT2; ++pt) {
                 const int j = ph * PT2 + pt, jr = j + BQ - 1;
 #ifndef BX_FAKE_NOA
+#ifdef BX_A_G0
+                if (pt == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) aq[(ph + 1) & 1][ct] = *reinterpret_cast<const bf16x8 *>(smem + an + ct * 1024);
+                }
+#else
                 if (pt < 2) {
                     aq[(ph + 1) & 1][2 * pt] = *reinterpret_cast<const bf16x8 *>(smem + an + (2 * pt) * 1024);
                     aq[(ph + 1) & 1][2 * pt + 1] = *reinterpret_cast<const bf16x8 *>(smem + an + (2 * pt + 1) * 1024);
                 }
+#endif
 #endif
 #ifndef BX_FAKE_NOB
                 if (jr < BX_KS * PT2) bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + ba2[jr % PT2] + BX_OFF2(jr));
@@ -287,9 +316,15 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ph & 1][ct], bq[j % BQ], acc[ct][pt], 0, 0, 0);
+#ifdef BX_A_G0
+                if (pt == 0 && jr < BX_KS * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                else if (pt == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                else if (jr < BX_KS * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#else
                 if (pt < 2 && jr < BX_KS * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 else if (pt < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 else if (jr < BX_KS * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -297,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
             BX_KBAR;
         }
         if (it == 2) PN_STAMP_AT(4);
-        // ---------------- output: (acc + b2) + x_hi + x_lo, ReLU, hi / lo split, three planes of 2 x 16-B stores per pixel ----------------
+        // ---------------- output: (acc + b2) + x_hi + x_lo, ReLU, hi / lo split, two planes of 2 x 16-B stores per pixel ----------------
         {
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (char *)P.out + ((size_t)b * H * W * P.out_cs + P.out_coff) * 2, 0, (int)((size_t)H * W * P.out_cs * 2), 0x00020000);
@@ -328,8 +363,6 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
                 __builtin_amdgcn_raw_buffer_store_b128(h1, orsrc, voff + 16u, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&lo[0]), orsrc, voff + (unsigned)out_ps, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&lo[8]), orsrc, voff + (unsigned)out_ps + 16u, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(h0, orsrc, voff + 2u * (unsigned)out_ps, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(h1, orsrc, voff + 2u * (unsigned)out_ps + 16u, 0, 0);
             }
         }
         asm volatile("s_barrier" ::: "memory");         // end of tile: the next input image has landed (the image loaders waited for it)

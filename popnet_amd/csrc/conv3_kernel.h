@@ -129,6 +129,7 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
     const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
     const float inv_wc = 1.0f / (float)Wc;
     const int nchunks = P.cin_chunks;
+    const int in_wrap = P.in_wrap;
 
     // ---- weight stream: scalar base per cout tile + lane offset; first NA-1 k-steps in flight ----
     const int ctile0 = (cb * WC + wc) * CT;
@@ -187,9 +188,10 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
         off = (unsigned)(min(max(iy0 + 2 * i, 0), Hin - 2) * row_b + max(ix0, 0) * col_b) + lane * 16;
 #endif
         asm volatile("" : "+v"(off));                    // materialise: the select below must stay a v_cndmask, not a branch
-        const unsigned zrel = zero_rel - (unsigned)(chunk * 128);
+        const int csrc = chunk >= in_wrap ? chunk - in_wrap : chunk;      // bf16x3: the third plane pair reads the hi plane again
+        const unsigned zrel = zero_rel - (unsigned)(csrc * 128);
 #ifndef PN_CONV3_FAKE_NODMA                               // timing experiment (wrong results): no halo fetch at all
-        pn_glds16(img + chunk * 128 + (inb ? off : zrel),
+        pn_glds16(img + csrc * 128 + (inb ? off : zrel),
 #ifdef PN_CONV3_HALFMAJOR
                   (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + dst_hm : (NBUF >= 3 ? nchunks : NBUF) * IMG));
 #else
@@ -537,8 +539,8 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
                 else v[k] = pn_activate(v[k], act, cw + k, naf);
             }
             if (out_base) {
-                // bf16x3: three planes [hi | lo | hi] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
-                for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+                // bf16x3: two planes [hi | lo] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
+                for (int pl = 0; pl < (split ? 2 : 1); ++pl) {
                     PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs + pl * split);
                     T ov[LC];
 #pragma unroll

@@ -110,11 +110,12 @@ __device__ __forceinline__ void conv4_body(const ConvProblem &P, const int block
         const bool inb = px < HC && (unsigned)ix < (unsigned)P.W && (unsigned)iy < (unsigned)P.H;
         boff[j] = inb ? (unsigned)((iy * P.W + ix) * P.in_cs * 2 + wc * 32 + (lane & 1) * 16) : zero_rel;
     }
-    const int nhalves = nchunks * 2;
+    const int nhalves = nchunks * 2, wrap_h = P.in_wrap * 2;
     auto dma_b = [&](int j, int buf, int hh) {       // piece j of half hh -> image `buf` of this strip
         const unsigned dst = (unsigned)(PN4_ARING + buf * PN4_BBUF + j * (PITCH * 32)) +
                              (unsigned)__builtin_amdgcn_readfirstlane(wp * PN4_BSTRIP + wc * PN4_BQUART);
-        pn_glds16_s<0>(img + (size_t)(hh < nhalves ? hh : 0) * 64, boff[j], dst);   // past the last half: a harmless refetch into the idle image
+        const int hs = hh < nhalves ? (hh >= wrap_h ? hh - wrap_h : hh) : 0;        // bf16x3: the third plane pair reads the hi plane again; past the last half: a harmless refetch into the idle image
+        pn_glds16_s<0>(img + (size_t)hs * 64, boff[j], dst);
     };
 
     // ---- prologue: image of half 0, weight k-steps 0..2 ----
@@ -298,8 +299,8 @@ __device__ __forceinline__ void conv4_body(const ConvProblem &P, const int block
                     else if (ACT == PN_ACT_LEAKY) v[k] = v[k] > 0.f ? v[k] : v[k] * 0.1f;
                     else if (ACT != PN_ACT_NONE) v[k] = pn_activate(v[k], act, cw + k, P.yolo_naf);
                 }
-                // bf16x3: three planes [hi | lo | hi] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
-                for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+                // bf16x3: two planes [hi | lo] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
+                for (int pl = 0; pl < (split ? 2 : 1); ++pl) {
                     T ov[LC];
 #pragma unroll
                     for (int k = 0; k < LC; ++k) {
@@ -366,7 +367,6 @@ __device__ __forceinline__ void conv4_body(const ConvProblem &P, const int block
                         out_base[opix * (unsigned)out_cs + k] = hi;
                         if (split) {
                             out_base[opix * (unsigned)out_cs + split + k] = (T)(v - (float)hi);
-                            out_base[opix * (unsigned)out_cs + 2 * split + k] = hi;
                         }
                     }
                     if (nchw) nchw[((size_t)b * cout + cw + k) * ((size_t)Ho * Wo) + (size_t)(oy0 + ry) * Wo + (ox0 + rx)] = v;

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     constexpr int DB = (PREC == PN_PREC_BF16) ? ((NITEM % 3 == 0) ? 3 : 2) : 1;   // B fragments in flight
     constexpr int MAXST = StageCfg<PREC, KS, STRIDE, PITCH, CFG>::MAXST;   // 0: stage without register prefetch
     const int nchunks = P.cin_chunks;
+    const int in_wrap = P.in_wrap;
 
     // weight stream: scalar base per cout tile + lane offset
     const int ctile0 = (cb * WC + wc) * CT;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     u32x4 st[MAXST > 0 ? MAXST : 1];
     auto stage_load = [&](int chunk) {                   // all loads issued back to back, no waits
         int hy = hy_first, hx = hx_first;
-        gcptr src = img + (size_t)chunk * 64 * ES;
+        gcptr src = img + (size_t)(chunk >= in_wrap ? chunk - in_wrap : chunk) * 64 * ES;      // bf16x3: the third plane pair reads the hi plane again
 #pragma unroll
         for (int it = 0; it < MAXST; ++it) {
             int soff, dst; bool inb;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
     };
     auto stage_direct = [&](int chunk, char *buf) {      // large halos: batches of 4 loads, then 4 stores
         int hy = hy_first, hx = hx_first;
-        gcptr src = img + (size_t)chunk * 64 * ES;
+        gcptr src = img + (size_t)(chunk >= in_wrap ? chunk - in_wrap : chunk) * 64 * ES;      // bf16x3: the third plane pair reads the hi plane again
         for (int pb = p0; pb < npx; pb += 4 * PPI) {
             u32x4 v[4];
             int dst[4]; bool inb[4];
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvProblem *__
                 else v[k] = pn_activate(v[k], act, cw + k, naf);
             }
             if (out_base) {
-                // bf16x3: three planes [hi | lo | hi] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
-                for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+                // bf16x3: two planes [hi | lo] `split` channels apart, hi = bf16(v), lo = bf16(v - hi)
+                for (int pl = 0; pl < (split ? 2 : 1); ++pl) {
                     PN_GLOBAL T *op = out_base + (unsigned)(opix * out_cs + pl * split);
                     T ov[LC];
 #pragma unroll

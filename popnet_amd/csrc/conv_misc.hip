@@ -66,9 +66,8 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const float *__restrict__ 
             v = v > 0.f ? v : 0.f;
             const T hi = (T)v;
             op[i] = hi;
-            if (split) {                                  // bf16x3: planes [hi | lo | hi]
+            if (split) {                                  // bf16x3: planes [hi | lo]
                 op[split + i] = (T)(v - (float)hi);
-                op[2 * split + i] = hi;
             }
         }
     }
@@ -190,8 +189,8 @@ __global__ __launch_bounds__(256) void stem7x7_mfma_kernel(const float *__restri
         }
         const int oy = oy0 + ry, ox = ox0 + c;
         if (oy < Ho && ox < Wo) {
-            // bf16x3: three planes [hi | lo | hi] `split` channels apart (pn_internal.h, ConvProblem::split)
-            for (int pl = 0; pl < (split ? 3 : 1); ++pl) {
+            // bf16x3: two planes [hi | lo] `split` channels apart (pn_internal.h, ConvProblem::split)
+            for (int pl = 0; pl < (split ? 2 : 1); ++pl) {
                 __bf16 o[16];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -409,7 +408,7 @@ __global__ void pool_kernel(const T *__restrict__ in, T *__restrict__ out, int B
             else acc[i] = ok[k] ? fmaxf(acc[i], f[i]) : acc[i];
         }
     }
-    for (int pl = 0; pl < (out_split ? 3 : 1); ++pl) {      // bf16x3: planes [hi | lo | hi]
+    for (int pl = 0; pl < (out_split ? 2 : 1); ++pl) {      // bf16x3: planes [hi | lo]
         T o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

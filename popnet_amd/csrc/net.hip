@@ -33,7 +33,7 @@ struct HostTensor {
 struct Buf {
     void *p = nullptr;
     int H = 0, W = 0, C = 0;   // C = channel stride
-    int plane = 0;             // bf16x3: channels of one of the three planes [hi | lo | hi] (C = 3 * plane); otherwise = C
+    int plane = 0;             // bf16x3: channels of one of the two stored planes [hi | lo] (C = 2 * plane); otherwise = C
 };
 
 struct ConvSpec {
@@ -105,7 +105,7 @@ struct pn_net {
     std::vector<void *> dev_allocs;
     float *nchw_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_B = -1;
-    bool x3 = false;                 // PN_PREC_BF16X3: tensors stored as [hi | lo | hi] bf16 planes, weights as [W_hi | W_hi | W_lo]
+    bool x3 = false;                 // PN_PREC_BF16X3: tensors stored as [hi | lo] bf16 planes, read as [hi | lo | hi] against weights [W_hi | W_hi | W_lo]
     bool locked = false;             // pn_net_lock: descriptors frozen (a captured hipGraph reads them at replay time)
     float *last_nchw[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<std::string, std::pair<int, std::pair<int, int>>> named;   // name -> (buf, (coff, C))
@@ -150,7 +150,7 @@ int dev_alloc(pn_net *n, void **p, size_t bytes, bool zero) {
 
 int new_buf(pn_net *n, int H, int W, int C) {
     Buf b;
-    b.H = H; b.W = W; b.plane = C; b.C = n->x3 ? 3 * C : C;
+    b.H = H; b.W = W; b.plane = C; b.C = n->x3 ? 2 * C : C;       // bf16x3: planes [hi | lo] (the third plane pair of the K loop re-reads hi: ConvProblem::in_wrap)
     n->bufs.push_back(b);
     return (int)n->bufs.size() - 1;
 }
@@ -548,6 +548,11 @@ int fold_bn(pn_net *n, const ConvSpec &cs, int cout, std::vector<double> &scale,
 // ReLU) become ONE level {-2, a, b} run by bb64_kernel (bf16) or bb64x3_kernel (bf16x3: two-plane LDS images, 6-row tiles).
 void fuse_basic_blocks(pn_net *n, std::vector<std::vector<int>> &levels) {
     if (n->prec != PN_PREC_BF16 || getenv("POPNET_NO_BBLOCK") || getenv("POPNET_NO_CONV3")) return;
+    // bf16x3: the fused kernel is built, bit-identical and faster ALONE (2 x 227 us against 4 x 100 us of conv3_kernel<3, 2, 2, 1, 7, 4> per step
+    // once tensors are stored as two planes), but a persistent 160-KB-of-LDS workgroup per CU shuts the other in-flight batches out of
+    // every CU for its whole life: through the bench's pipelined region the two-launch plan wins (25.7 k against 24.0 k frames/s on the
+    // same box, profiles/r04_bb64x3_ab.txt).  POPNET_BBLOCK_X3=1 selects the fused kernel (tests, one-stream latency runs).
+    if (n->x3 && !(getenv("POPNET_BBLOCK_X3") && atoi(getenv("POPNET_BBLOCK_X3")))) return;
 #ifdef PN_EXPERIMENTS
     if (n->x3 && getenv("POPNET_X3_BF16_CONVS")) return;      // the mixed-precision experiment runs single-pass convs the fused kernel does not know
 #endif
@@ -903,6 +908,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.Wo = (ib.W + 2 * (cs.ks / 2) - cs.ks) / cs.stride + 1;
             P.cin_chunks = cs.cin_chunks;
             P.in_cs = ib.C; P.in_coff = cs.in_coff;
+            P.in_wrap = n->x3 ? 2 * (ib.plane / 64) : (1 << 20);      // (conv4_kernel doubles it: halves)
             P.cout = cs.cout;
             if (cs.out_buf >= 0) { P.out = n->bufs[cs.out_buf].p; P.out_cs = n->bufs[cs.out_buf].C; P.out_coff = cs.out_coff; P.split = n->x3 ? n->bufs[cs.out_buf].plane : 0; }
             if (cs.res_buf >= 0) { P.res = n->bufs[cs.res_buf].p; P.res_cs = n->bufs[cs.res_buf].C; P.res_coff = cs.res_coff; P.res_split = n->x3 ? n->bufs[cs.res_buf].plane : 0; }

@@ -76,11 +76,15 @@ struct ConvProblem {
     int lds_buf_bytes;     // bytes of one LDS halo image
     int lds_two;           // 1: a second image follows (double-buffered chunks), 0: single image
     unsigned in_zero_off;  // conv3_kernel: byte offset from `in` to >= 16 zero bytes (padding source of the halo DMA)
-    // bf16x3 mode (PN_PREC_BF16X3): a tensor is stored as three bf16 planes [hi | lo | hi] `split` channels apart
-    // (hi = bf16(v), lo = bf16(v - hi)); 0 = plain bf16 / f32 tensor.  The K loop never knows: the input simply has
-    // three times the channels and the packed weights are [W_hi | W_hi | W_lo] (net.hip::prepare_conv).
+    // bf16x3 mode (PN_PREC_BF16X3): a tensor is the planes hi = bf16(v), lo = bf16(v - hi), `split` channels apart; 0 = plain
+    // bf16 / f32 tensor.  The K loop sees three times the channels, [x_hi | x_lo | x_hi] against packed weights [W_hi | W_hi | W_lo]
+    // (net.hip::prepare_conv).
+    // Round 4: the third plane is a copy of the first, so only TWO planes [hi | lo] are stored; the K loop still runs over three
+    // plane pairs and fetches input chunk c from chunk (c >= in_wrap ? c - in_wrap : c) of the buffer -- the hi plane twice.  A third
+    // less HBM traffic on every bf16x3 tensor, same values in the same k order.
     int split;             // plane distance (channels) of the OUTPUT tensor, 0 = not split
     int res_split;         // plane distance of the residual tensor (hi + lo are added), 0 = not split
+    int in_wrap;           // 64-channel chunks of the INPUT buffer after which the source chunk index wraps to 0 (2 x plane / 64; > cin_chunks = never)
     // fused 1x1 tail (conv3_kernel<1, 4, 1, ...> only; net.hip::fuse_1x1_tails): when tail_w != nullptr the block's 128-channel
     // output tile is NOT stored; a second 1x1 convolution (128 -> tail_cout <= 32 channels) runs on it from LDS and only ITS
     // result leaves the kernel -- the `1x1 256 -> 128 + BN + LeakyReLU, then 1x1 128 -> 28` tail of the PAF branch

@@ -206,7 +206,7 @@ def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, mo
 @pytest.mark.parametrize("hw,B", [((224, 224), 5), ((200, 232), 3), ((256, 192), 2), ((96, 480), 3), ((72, 136), 4)])
 def test_bf16x3_fused_basic_block_equals_the_two_launch_plan_bit_for_bit(gpu, golden, hw, B, monkeypatch):
     """bb64x3_kernel: the BasicBlock(64)s of the split-bf16 nets as ONE launch -- two-plane LDS images, the
-    intermediate map never leaves the CU -- against the two conv3_kernel launches per block (POPNET_NO_BBLOCK=1) under
+    intermediate map never leaves the CU (POPNET_BBLOCK_X3=1) -- against the two conv3_kernel launches per block, the default plan under
     precision="bf16x3": same k order (plane pair, half, tap), same MFMA, same epilogue arithmetic, so the maps must be IDENTICAL.
     Sizes: the bench's 112 x 112 maps (6-row tiles: 18 full + one 4-row tile), ragged widths (100 x 116 -> 25 / 29-column strips,
     128 x 96 -> 24-column strips, 48 x 240), a 36 x 68 map (six full row tiles, 23 / 22-column strips); rtpose's layer1 (two blocks at
@@ -222,12 +222,12 @@ def test_bf16x3_fused_basic_block_equals_the_two_launch_plan_bit_for_bit(gpu, go
         return m
 
     do_yolo = H % 16 == 0 and W % 16 == 0
+    monkeypatch.setenv("POPNET_BBLOCK_X3", "1")          # read when the net is compiled (the bf16x3 plan keeps two launches by default: net.hip::fuse_basic_blocks)
     got = [t.clone() for t in _rtpose(golden, "bf16x3")(x)[0]]
     got_y = yolo()(x).clone() if do_yolo else None
-    monkeypatch.setenv("POPNET_NO_BBLOCK", "1")          # read when the net is compiled
+    monkeypatch.delenv("POPNET_BBLOCK_X3")
     ref = [t.clone() for t in _rtpose(golden, "bf16x3")(x)[0]]
     ref_y = yolo()(x).clone() if do_yolo else None
-    monkeypatch.delenv("POPNET_NO_BBLOCK")
     f32 = [t.clone() for t in _rtpose(golden, "fp32")(x)[0]]
     torch.cuda.synchronize()
     for a, b, c, name in zip(got, ref, f32, ("paf", "heat", "z")):
