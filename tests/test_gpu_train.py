@@ -558,7 +558,7 @@ def test_synthetic_train_eval_script_runs(gpu, capsys, monkeypatch):
     assert out["eval"]["bf16x3"]["vs_fp32"]["same_person_count"] >= 30
 
 
-def test_trained_checkpoint_bf16x3_equals_fp32_on_every_held_out_frame(gpu, capsys, monkeypatch):
+def test_trained_checkpoint_bf16x3_equals_fp32_on_every_held_out_frame_and_bf16_is_what_the_docs_say(gpu, capsys, monkeypatch):
     """the flip rate of the tolerance-meeting fast mode is ZERO where it should be -- on the maps of a
     TRAINED checkpoint, whose peaks stand clear of the detection threshold.  scripts/synthetic_train_eval.py at 1 500 steps
     (17 s of training on the GPU, hipGraph replay of TrainEngine in bf16x3 mode): synthetic stick-figure scenes -> compositor ->
@@ -578,6 +578,14 @@ def test_trained_checkpoint_bf16x3_equals_fp32_on_every_held_out_frame(gpu, caps
     v = ev["bf16x3"]["vs_fp32"]
     assert v["same_person_count"] == 96 and v["same_assignment"] == 96 and v["d3_m_max"] < 1e-3, v
     assert ev["bf16x3"]["persons_found"] == ev["fp32"]["persons_found"] and ev["bf16x3"]["pckh_2d_mean"] == ev["fp32"]["pckh_2d_mean"]
+    # the HEADLINE dtype on the same trained checkpoint, pinned to the measured figures (the run is deterministic:
+    # two runs on two boxes gave identical numbers) -- same person count in 96 / 96 held-out frames, same assignment in 94 / 96, median 3D
+    # difference 0.37 mm, task accuracy PCKh-2D 0.9315 against 0.9283 for fp32.  What bf16 does NOT give is the 1e-3 m bound on every
+    # joint (max 6.7 cm on one joint of one frame): it is the throughput mode, and bench.py prints its fidelity next to `value`.
+    b = ev["bf16"]["vs_fp32"]
+    assert b["same_person_count"] >= 95 and 92 <= b["same_assignment"] <= 96, b
+    assert 0.9 * 3.708e-4 <= b["d3_m_median"] <= 1.1 * 3.708e-4, b
+    assert abs(ev["bf16"]["pckh_2d_mean"] - ev["fp32"]["pckh_2d_mean"]) < 0.01 and ev["bf16"]["pckh_2d_mean"] > 0.85, (ev["bf16"], ev["fp32"])
 
 
 def test_conv_primitives_random_shapes(gpu):
