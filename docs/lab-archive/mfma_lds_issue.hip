@@ -1,7 +1,7 @@
 // Development tool (not part of the product): what does ONE ds_read_b128 (or one LDS-DMA instruction) cost a wave that is
 // otherwise issuing nothing but MFMAs?  The conv4_kernel ablations (profiles/r02_conv4_ablations.txt) price the 11 fragment
 // reads of a 28-MFMA k-step at 147 cycles; this isolates the effect per MFMA shape.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/experiments/mfma_lds_issue.hip -o popnet_amd/build/mfma_lds_issue
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 docs/lab-archive/mfma_lds_issue.hip -o popnet_amd/build/mfma_lds_issue
 // Per variant: cycles per k-step (= 28 x 16x16x32 or 14 x 32x32x16 MFMAs, 448 cycles of matrix-pipe time either way) with
 // NR fragment reads interleaved, at 1 and 2 waves per SIMD, every CU busy.
 #include <hip/hip_runtime.h>

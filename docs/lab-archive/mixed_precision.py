@@ -2,7 +2,7 @@
 """Per-layer mixed precision inside the bf16x3 net ("look for a cheaper tolerance-meeting configuration"):
 POPNET_X3_BF16_CONVS runs the named convolutions as plain bf16 (one MFMA pass on the hi plane instead of three); every
 configuration is compared with the fp32 engine on 96 frames of both synthetic weight sets (popnet_amd.fidelity) and timed
-(one engine, eager).  Usage (GPU box): python scripts/experiments/mixed_precision.py"""
+(one engine, eager).  Usage (GPU box): python docs/lab-archive/mixed_precision.py"""
 import json
 import os
 import sys

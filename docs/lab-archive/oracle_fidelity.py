@@ -4,7 +4,7 @@ per synthetic weight set (calibrate_heads gain 1 = heat values crowd the detecti
 (gain, precision): frames with identical person assignment, max 3D difference on those, and whether every differing frame is
 FRAGILE -- a frame whose ORACLE result itself changes when its fp32 maps are perturbed by one part in 1e5 (the size of the
 difference between any two fp32 summation orders).  Feeds the assertions of tests/test_gpu_precision.py.
-Usage (GPU box): python scripts/experiments/oracle_fidelity.py [frames]"""
+Usage (GPU box): python docs/lab-archive/oracle_fidelity.py [frames]"""
 import os
 import sys
 

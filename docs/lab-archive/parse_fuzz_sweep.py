@@ -1,6 +1,6 @@
 """One-off wide fuzz of the GPU pose parse against the oracle (the committed test runs a handful of settings):
 many seeds x noise levels x drop probabilities x blob widths, 16 frames each; prints every mismatch.
-Run from the repo root on the GPU box:  python3 scripts/experiments/parse_fuzz_sweep.py [n_seeds]"""
+Run from the repo root on the GPU box:  python3 docs/lab-archive/parse_fuzz_sweep.py [n_seeds]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np

@@ -1,6 +1,6 @@
 """One-off wide fuzz of the GPU YOLO decode (parse_prior_pose) against the oracle: many seeds x confidence ranges (sparse to
 dense candidate sets, near-threshold confidences, heavy box overlap for the NMS keep-loop quirk).
-Run from the repo root on the GPU box:  python3 scripts/experiments/yolo_fuzz_sweep.py [n_seeds]"""
+Run from the repo root on the GPU box:  python3 docs/lab-archive/yolo_fuzz_sweep.py [n_seeds]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np

@@ -1019,7 +1019,7 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         }
         // timing-only ablation (wrong results): POPNET_ABLATE_SKIP = comma-separated classes of launches to skip --
         // "pool", "head" (<= 32-cout generic launches), "c1x1" (conv3 1x1), "c3" (conv3 3x3), "stem"; what would the pipelined
-        // throughput be if these launches cost nothing?  (scripts/experiments/tail_ablation.sh)
+        // throughput be if these launches cost nothing?  (docs/lab-archive/tail_ablation.sh)
 #ifdef PN_EXPERIMENTS      // lab builds only: a timed region of the shipped library cannot be made to skip launches by the environment
         static const char *skip = getenv("POPNET_ABLATE_SKIP");
         if (skip) {

@@ -1,6 +1,6 @@
 """Random-shape sweep of the training convolution primitives (forward, data gradient, weight / bias gradient) against torch CPU,
 both precision modes: ragged channel counts, maps narrower / wider than a tile, 1-row maps, batch 1..5.
-usage: python scripts/experiments/train_conv_fuzz.py [cases = 120] [seed = 0]"""
+usage: python scripts/train_conv_fuzz.py [cases = 120] [seed = 0]"""
 import ctypes as C
 import os
 import sys

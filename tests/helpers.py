@@ -135,7 +135,7 @@ def sample_indices(name, numel, n=48):
     return np.sort(rng.choice(numel, size=min(n, numel), replace=False))
 
 
-# ---- engines against the CPU oracle, end to end (tests/test_gpu_precision.py, scripts/experiments/oracle_fidelity.py) ----
+# ---- engines against the CPU oracle, end to end (tests/test_gpu_precision.py, docs/lab-archive/oracle_fidelity.py) ----
 def _oracle_signature(ref):
     """(peak count, person -> peak-id table) of one oracle frame: what 'bit-exact person assignment' compares."""
     assoc = np.asarray(ref["assoc"]).reshape(-1, 17)

@@ -10,7 +10,7 @@ What that bar can and cannot mean.  ReLU / LeakyReLU backward multiplies by a 0/
 pre-activation.  Two correct fp32 evaluations (this one and torch's, or torch's fp32 and its own fp64) differ by ~1e-7
 relative in those pre-activations, so among millions of them a few land on different sides of zero; each such flip changes
 the gradient of everything upstream by ~1 / sqrt(elements of that layer) ~ 2e-3 relative -- a discrete event, not an
-accuracy defect.  Measured (scripts/experiments/train_grad_errors.py): at a size with 250 k activations 5 of 6 seeds have NO
+accuracy defect.  Measured (docs/lab-archive/train_grad_errors.py): at a size with 250 k activations 5 of 6 seeds have NO
 flip and then every tensor agrees to 2e-6; at 224 x 224 torch's OWN fp32 differs from its fp64 by 1e-3..8e-3 on whole branches.
 Hence two kinds of test: (1) strict 1e-4 per tensor, no exceptions, at a flip-free size (the arithmetic is right);
 (2) at the training configuration's size and on the reference goldens: the error against fp64 autograd must be in the
@@ -589,11 +589,11 @@ def test_trained_checkpoint_bf16x3_equals_fp32_on_every_held_out_frame_and_bf16_
 
 
 def test_conv_primitives_random_shapes(gpu):
-    """scripts/experiments/train_conv_fuzz.py at test length: 40 random (N, Cin, Cout, H, W, kernel, padding) cases -- ragged channel
+    """scripts/train_conv_fuzz.py at test length: 40 random (N, Cin, Cout, H, W, kernel, padding) cases -- ragged channel
     counts, maps narrower and wider than a tile, one-row maps -- forward, data gradient, weight and bias gradient against torch
     in both precision modes (a 150-case run: worst relative error 1.5e-6 in fp32, 4.7e-6 in bf16x3)."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("train_conv_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "experiments", "train_conv_fuzz.py"))
+    spec = importlib.util.spec_from_file_location("train_conv_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "train_conv_fuzz.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     worst = mod.run(40, seed=7, verbose=False)
