@@ -59,6 +59,8 @@ struct ConvSpec {
     bool fused_away = false;  // this conv runs as the tail of another one: it has no launch of its own
     void *tail_wpack = nullptr;
     float *tail_bias = nullptr;
+    bool embed3 = false;      // a 1x1 convolution run as the centre tap of a 3x3 one (zero weights elsewhere: the same sums, exact zeros added), so that it shares
+                              // the launch of a 3x3 sibling of the same stride: YoloPoseNet's layer2.0 stride-2 shortcut (resnet.py:59-77, build_yolo)
     bool pool_tail = false;   // fuse_pool_tails: the AvgPool2d(3, 2, 1) that follows runs inside this conv's launch (conv3_kernel<1, 4, 1, 1, 7, 8, 2>)
     int pool_out_buf = -1, pool_out_coff = 0;
 };
@@ -175,9 +177,10 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const HostTensor *w = find_t(n, cs.w + ".weight");
     if (!w || w->shape.size() != 4)
         return pn_set_error(ctx, PN_ERR_INVALID, "missing conv weight %s.weight", cs.w.c_str());
-    const int cout = (int)w->shape[0], cin_ref = (int)w->shape[1], ks = (int)w->shape[2];
-    if (ks != cs.ks || (int)w->shape[3] != ks)
-        return pn_set_error(ctx, PN_ERR_INVALID, "%s.weight: kernel %dx%d, expected %d", cs.w.c_str(), ks, (int)w->shape[3], cs.ks);
+    const int cout = (int)w->shape[0], cin_ref = (int)w->shape[1], wks = (int)w->shape[2];
+    const int ks = cs.embed3 ? 3 : wks;
+    if ((cs.embed3 ? wks != 1 : wks != cs.ks) || (int)w->shape[3] != wks || ks != cs.ks)
+        return pn_set_error(ctx, PN_ERR_INVALID, "%s.weight: kernel %dx%d, expected %d", cs.w.c_str(), wks, (int)w->shape[3], cs.embed3 ? 1 : cs.ks);
     cs.cout = cout;
     std::vector<int> map = cs.cin_map;
     if (map.empty()) {
@@ -250,7 +253,8 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     auto wval = [&](int co, int idx, int tap) -> float {      // folded weight of packed input channel idx
         const int ci = map[idx];
         if (co >= cout || ci < 0) return 0.f;
-        const float v = (float)((double)w->data[((size_t)co * cin_ref + ci) * (ks * ks) + tap] * scale[co]);
+        if (cs.embed3 && tap != 4) return 0.f;
+        const float v = (float)((double)w->data[cs.embed3 ? (size_t)co * cin_ref + ci : ((size_t)co * cin_ref + ci) * (ks * ks) + tap] * scale[co]);
         if (!n->x3) return v;
         uint32_t hb = (uint32_t)f32_to_bf16(v) << 16;
         float hi;
@@ -351,7 +355,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
     if (cs.kern == 3 || cs.kern == 4) {
         cs.pitch = 32;
-        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
+        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * (cs.embed3 ? 1 : KK);
         if (cs.out_buf >= 0) {
             const Buf &ob = n->bufs[cs.out_buf];
             if (ob.H != Ho || ob.W != Wo) return pn_set_error(ctx, PN_ERR_INVALID, "%s: output buffer is %dx%d, conv gives %dx%d", cs.w.c_str(), ob.H, ob.W, Ho, Wo);
@@ -373,7 +377,7 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     }
     cs.pitch = pick_pitch((cs.Wt - 1) * cs.stride + ks);
     if (cs.pitch < 0) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo width %d has no pitch class", cs.w.c_str(), (cs.Wt - 1) * cs.stride + ks);
-    cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * KK;
+    cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * (cs.embed3 ? 1 : KK);
     if (cs.out_buf >= 0) {
         const Buf &ob = n->bufs[cs.out_buf];
         if (ob.H != Ho || ob.W != Wo) return pn_set_error(ctx, PN_ERR_INVALID, "%s: output buffer is %dx%d, conv gives %dx%d", cs.w.c_str(), ob.H, ob.W, Ho, Wo);
@@ -851,8 +855,15 @@ int build_yolo(pn_net *n) {
         level({add_conv(n, p + ".conv2", p + ".bn2", 3, 1, XT, 0, other, 0, PN_ACT_RELU, cur)});
         std::swap(cur, other);
     }
-    level({add_conv(n, "model0.layer2.0.conv1", "model0.layer2.0.bn1", 3, 2, cur, 0, YT, 0, PN_ACT_RELU),
-           add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", 1, 2, cur, 0, YD, 0, PN_ACT_NONE)});
+    {   // layer2.0: the 3x3 stride-2 conv and its 1x1 stride-2 shortcut (resnet.py:59-77) read the same map at the same stride.  bf16 / bf16x3: the
+        // shortcut runs as the centre tap of a 3x3 problem in the SAME launch (one launch and 12 us of pure latency less per step; every added
+        // product is an exact zero, so the sums are the 1x1 convolution's bit for bit: POPNET_NO_EMBED3=1 keeps the two launches, tested)
+        const bool embed = n->prec == PN_PREC_BF16 && !getenv("POPNET_NO_EMBED3");
+        const int c1 = add_conv(n, "model0.layer2.0.conv1", "model0.layer2.0.bn1", 3, 2, cur, 0, YT, 0, PN_ACT_RELU);
+        const int cd = add_conv(n, "model0.layer2.0.downsample.0", "model0.layer2.0.downsample.1", embed ? 3 : 1, 2, cur, 0, YD, 0, PN_ACT_NONE);
+        n->convs[cd].embed3 = embed;
+        level({c1, cd});
+    }
     level({add_conv(n, "model0.layer2.0.conv2", "model0.layer2.0.bn2", 3, 1, YT, 0, Y0, 0, PN_ACT_RELU, YD)});
     int yc = Y0, yo = Y1;
     for (int i = 1; i < 4; ++i) {

@@ -16,7 +16,7 @@ python3 scripts/make_traffic_json.py $O $O/conv_hbm_traffic.json | tail -30
 i=0
 for set in "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_TA_BUSY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc/pass$i -o runc -- python3 bench.py --steps 20 --warmup 4 --reps 1 --no-h2d --no-extras --no-cpu-baseline --no-graph > $O/pmc/pass$i.log 2>&1
+  mkdir -p $O/pmc; rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc/pass$i -o runc -- python3 bench.py --steps 20 --warmup 4 --reps 1 --no-h2d --no-extras --no-cpu-baseline --no-graph > $O/pmc/pass$i.log 2>&1
 done
 python3 scripts/pmc_kernel_table.py $O/pmc | tee $O/pmc_table.txt
 for d in stats stats_eager1 stats_x3_eager1 stats_yolo_eager1; do f=$(ls $O/$d/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$d.csv; done
