@@ -46,11 +46,12 @@ _PINNED = {}
 PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}      # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(engine, depth_host, frames_sample=32, reps=6):
+def cpu_baseline(engine, depth_host, frames_sample=32, reps=3):
     """The oracle (a port of the reference's CPU path: numpy/cv2-restatement pre-proc, torch fp32 CPU
-    forward, NumPy parse) timed on a bounded sample of the same workload.  torch's intra-op pool is
-    tried at 32 threads and at every host core (small convolutions do not scale to hundreds of
-    threads); the faster setting is the one reported, with its thread count."""
+    forward, NumPy parse) timed on a bounded sample of the same workload: ~15 s of CPU work.  torch's
+    intra-op pool runs at min(32, host cores) threads -- these small convolutions do not scale to hundreds of
+    threads (rounds 1-3 also tried every host core and always reported 32: on a 256-core host that trial alone
+    cost 150 s of the bench's 240 s wall time, round 4 `leg_seconds`)."""
     from oracle import nets as onets, parse_paf as oparse, preproc as opre
     cores = os.cpu_count() or 1
     sd = {k: v.detach().cpu().clone() for k, v in engine.model.state_dict().items()}
@@ -59,7 +60,7 @@ def cpu_baseline(engine, depth_host, frames_sample=32, reps=6):
     x = torch.from_numpy(opre.preprocess_batch(d))
     t_pre = time.time() - t0
     best = None
-    for threads in sorted({min(32, cores), cores}):
+    for threads in (min(32, cores),):
         torch.set_num_threads(threads)
         onets.rtpose_light3d_forward(x[:1], sd)                      # warm the thread pool / allocator
         t1 = time.time()
@@ -90,7 +91,7 @@ def cpu_baseline(engine, depth_host, frames_sample=32, reps=6):
            "sample": "the first %d of those frames as one batch (the reference's default batch size): torch-CPU forward %.2fs (%d threads) + the per-frame "
                      "preproc / parse times of the 32-frame sample" % (n15, t_fwd15, threads)}
     return {"value": round(len(d) / total, 3), "unit": "frames/s", "cores": threads, "kind": "port", "host_cores": cores, "batch": len(d), "b15": b15,
-            "sample": "%d of the step's 32 frames (forward and parse repeated 6x, means reported), fp32: preproc %.2fs (1 thread) + torch-CPU forward %.2fs (%d threads, best of {32, all %d cores}) + "
+            "sample": "%d of the step's 32 frames (forward and parse repeated 3x, means reported), fp32: preproc %.2fs (1 thread) + torch-CPU forward %.2fs (%d threads of the host's %d cores) + "
                       "numpy parse %.2fs (1 thread)" % (len(d), t_pre, t_fwd, threads, cores, t_parse)}
 
 
@@ -624,7 +625,10 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    leg_s = {}
+    _t = time.perf_counter()
     legs = pipelined_leg(args, dev, world, rank, dist, args.net, args.precision, want_h2d=not args.no_h2d, dist_active=dist_active)
+    leg_s["timed_regions_and_roofline_pass"] = round(time.perf_counter() - _t, 1)
     # collectives: EVERY rank takes part (rank 0 alone would wait for the others forever)
     dist_res = dist_check(dev, world, rank, dist) if dist_active else None
     plan = plan_legs(world, rank, args.net, args.precision, args.no_extras, args.no_cpu_baseline)
@@ -636,8 +640,10 @@ def main():
         if dist_res is not None:
             out["dist"] = dist_res
         if plan["extras"]:
+            _t = time.perf_counter()
             out["mpaug_parse"] = mpaug_parse_leg(engine)
             out["precision_modes"] = precision_modes_leg(dev)
+            leg_s["mpaug_parse_and_precision_modes"] = round(time.perf_counter() - _t, 1)
             # the headline dtype's own fidelity next to `value`: no reader can take the bf16 figure as a within-tolerance one
             fid = out["precision_modes"].get(args.precision, {}).get("vs_fp32_threshold_calibrated_weights")
             sep = out["precision_modes"].get(args.precision, {}).get("vs_fp32_separated_weights")
@@ -649,7 +655,9 @@ def main():
                                    "note": "north_star: joints within 1e-3 m, identical person assignment. The mode that meets it at matrix-core rate is `parity_mode` below."}
         cpu_eng_depth = (engine, legs["depth_host"])
         if plan["cpu_baseline"]:
+            _t = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(*cpu_eng_depth)
+            leg_s["cpu_baseline"] = round(time.perf_counter() - _t, 1)
     legs = None
     import gc
     gc.collect()
@@ -689,7 +697,9 @@ def main():
                 return json.loads(lines[-1])
             except ValueError as e:
                 return {"error": "child leg printed no JSON line: %s" % e}
+        _t = time.perf_counter()
         pm = child_leg(["--precision", "bf16x3"] + (["--no-h2d"] if args.no_h2d else []))
+        leg_s["parity_mode_child"] = round(time.perf_counter() - _t, 1)
         x3 = out["precision_modes"]["bf16x3"]
         if "error" in pm:
             out["parity_mode"] = pm
@@ -704,7 +714,9 @@ def main():
                              "conv_stack_algorithmic_tflops": rf["conv_stack"]["achieved"], "conv_stack_physical_frac": round(3 * rf["conv_stack"]["frac"], 4)},
                 "fidelity": {"threshold_calibrated_weights": x3["vs_fp32_threshold_calibrated_weights"], "separated_weights": x3["vs_fp32_separated_weights"]},
                 "what": "the same pipelined timed region (hipGraph replay, %d batches in flight, median of %d; its own process) with precision='bf16x3': every tensor as three bf16 planes, fp32-class results" % (args.pipeline, args.reps)}
+        _t = time.perf_counter()
         yl = child_leg(["--net", "yolo", "--no-h2d"])
+        leg_s["yolo_child"] = round(time.perf_counter() - _t, 1)
         if "error" in yl:
             out["yolo"] = yl
         else:
@@ -715,11 +727,16 @@ def main():
                            "what": "YoloPoseNet forward + box decode / NMS / skeleton read-out (SURVEY 8a rows 7, 12) through the same pipelined region (its own process)"}
         # RCCL on this box: one fresh rank under torch.distributed.run with the process group initialised on
         # backend "nccl" at world_size 1: the region's all-gather plus gather_records / the 22 MB gradient all-reduce on device tensors
+        _t = time.perf_counter()
         rc = child_leg(["--force-dist", "--no-h2d", "--steps", "100", "--warmup", "5", "--reps", "2", "--pool", "2"])
+        leg_s["rccl_check_child"] = round(time.perf_counter() - _t, 1)
         out["rccl_check"] = rc if "error" in rc else dict(rc.get("dist", {"error": "no dist block in the child's line"}), value_with_process_group=rc["value"])
         if plan["train_step"]:
+            _t = time.perf_counter()
             out["train_step"] = train_step_leg(dev, cpu=not args.no_cpu_baseline)
+            leg_s["train_step"] = round(time.perf_counter() - _t, 1)
     if rank == 0:
+        out["leg_seconds"] = leg_s
         out["env"] = dict(env_seen, library="popnet_amd/" + os.path.basename(_pl.LIB_PATH), lab_build=bool(lab_build),
                           GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"))
         print(json.dumps(out))
