@@ -303,6 +303,14 @@ int pn_train_set_precision(pn_ctx *ctx, int precision);
 /* keep != 0: a hipGraph captured from the training primitives points into the context's scratch; from now on a call that
  * needs a larger scratch retires the old block (freed by pn_destroy) instead of freeing it, so the graph stays replayable. */
 int pn_train_ws_keep(pn_ctx *ctx, int keep);
+/* Weight-pack cache of the 3x3 training convolutions (round 4).  Off (default): pn_conv2d_forward / _dgrad re-pack their weights
+ * (transpose / rotate / split) into the context's scratch on every call.  On: the packs live in persistent buffers keyed by (weight
+ * pointer, shape, rotation, precision); pn_train_pack_refresh re-packs ALL of them in one launch (call it once per step, before the
+ * first convolution: popnet_amd.train.TrainEngine does), pn_sgd_nesterov marks them stale, a stale or unknown pack is rebuilt by the
+ * call that needs it.  Weights changed by anything but pn_sgd_nesterov need a refresh before the next convolution.  Replaces the
+ * 62 pack launches per step of train_rtpose_light3d_kdh3d_mpaug.py:160-180's forward / backward (tpm/lib/network/rtpose_light3d.py). */
+int pn_train_pack_cache(pn_ctx *ctx, int enable);
+int pn_train_pack_refresh(pn_ctx *ctx, void *hip_stream);
 int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const float *bias_dev, float *y_dev, int N, int Cin,
                       int H, int W, int Cout, int ks, int stride, int pad, int accumulate, void *hip_stream);
 int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float *dx_dev, int N, int Cin, int H, int W, int Cout,

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "pn_rasterize_targets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, C.POINTER(TargetCfg), _vp, _vp, _vp, _vp, _vp]),
     "pn_train_set_precision": (_i, [_vp, _i]),
     "pn_train_ws_keep": (_i, [_vp, _i]),
+    "pn_train_pack_cache": (_i, [_vp, _i]),
+    "pn_train_pack_refresh": (_i, [_vp, _vp]),
     "pn_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "pn_conv2d_dgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "pn_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),

@@ -67,6 +67,8 @@ void pn_destroy(pn_ctx *ctx) {
     pn_parse_big_free(ctx);
     if (ctx->train_ws) (void)hipFree(ctx->train_ws);
     for (void *p : ctx->train_ws_retired) (void)hipFree(p);
+    for (auto &e : ctx->train_packs) (void)hipFree(e.buf);
+    if (ctx->train_pack_table) (void)hipFree(ctx->train_pack_table);
     delete ctx;
 }
 

@@ -22,6 +22,15 @@ struct pn_ctx {
     std::vector<void *> train_ws_retired;
     bool train_lds_attr = false;     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the tile kernels on this device
     bool train_x3 = false;           // pn_train_set_precision: 3x3 forward / data-gradient convolutions on split-bf16 MFMA
+    // pn_train_pack_cache: the packed (transposed / rotated / split) weights of the 3x3 training convolutions live in persistent buffers keyed by
+    // (weight pointer, shape, flip, precision) and are all refreshed by ONE launch per step (pn_train_pack_refresh) instead of one launch per
+    // convolution call (train.hip)
+    struct PackEntry { const float *w; int Cout, Cin, flip, x3; void *buf; size_t bytes; bool fresh; };
+    bool train_pack_cache = false;
+    std::vector<PackEntry> train_packs;
+    void *train_pack_table = nullptr;      // device copy of the descriptor table
+    size_t train_pack_table_entries = 0;   // entries the device table holds (re-uploaded when the host list has grown)
+    unsigned train_pack_blocks = 0;
 };
 
 int pn_set_error(pn_ctx *ctx, int code, const char *fmt, ...);

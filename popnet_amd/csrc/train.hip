@@ -427,6 +427,57 @@ __global__ void wpack3_x3_kernel(const float *__restrict__ w, __bf16 *__restrict
     wpx[plane + i] = (__bf16)(v - (float)h);
 }
 
+// Every cached pack of a context refreshed by ONE launch (pn_train_pack_refresh): the block finds its descriptor (<= ~70 entries, scanned by
+// every thread: uniform) and runs wpack3_kernel's / wpack3_x3_kernel's element arithmetic on it -- the same values as the per-call packs.
+struct TPackDesc { const float *w; void *dst; int Cout, Cin, flip, x3; unsigned first_block, pad; };
+__global__ void wpack_all_kernel(const TPackDesc *__restrict__ tab, int n) {
+    int e = 0;
+    while (e + 1 < n && blockIdx.x >= tab[e + 1].first_block) ++e;
+    const TPackDesc d = tab[e];
+    const size_t i = (size_t)(blockIdx.x - d.first_block) * blockDim.x + threadIdx.x;
+    const int Cout = d.Cout, Cin = d.Cin;
+    if (d.x3) {
+        const int chunks = (Cin + 31) / 32;
+        const size_t plane = (size_t)chunks * 9 * Cout * 32;
+        if (i >= plane) return;
+        const int ch = (int)(i & 31), co = (int)((i >> 5) % Cout), tap = (int)(((i >> 5) / Cout) % 9), chunk = (int)((i >> 5) / Cout / 9);
+        const int ci = chunk * 32 + ch;
+        float v = 0.f;
+        if (ci < Cin) v = d.flip ? d.w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : d.w[((size_t)co * Cin + ci) * 9 + tap];
+        const __bf16 h = (__bf16)v;
+        __bf16 *wpx = (__bf16 *)d.dst;
+        wpx[i] = h;
+        wpx[plane + i] = (__bf16)(v - (float)h);
+    } else {
+        if (i >= (size_t)9 * Cin * Cout) return;
+        const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), tap = (int)(i / ((size_t)Cout * Cin));
+        ((float *)d.dst)[i] = d.flip ? d.w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : d.w[((size_t)co * Cin + ci) * 9 + tap];
+    }
+}
+
+static int t_ws(pn_ctx *ctx, size_t bytes, void **out);
+// The pack buffer of (w, shape, flip, precision): the context's scratch when the cache is off (packed by the caller on every call), else
+// the cached entry -- *fresh tells the caller whether this step's refresh has already filled it.
+static int t_pack_get(pn_ctx *ctx, const float *w, int Cout, int Cin, int flip, int x3, size_t bytes, hipStream_t s, void **buf, bool *fresh) {
+    *fresh = false;
+    if (!ctx->train_pack_cache) return t_ws(ctx, bytes, buf);
+    for (auto &e : ctx->train_packs)
+        if (e.w == w && e.Cout == Cout && e.Cin == Cin && e.flip == flip && e.x3 == x3) {
+            *buf = e.buf; *fresh = e.fresh; e.fresh = true;           // (a stale entry is packed by the caller right now)
+            return PN_OK;
+        }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap != hipStreamCaptureStatusNone)
+        return pn_set_error(ctx, PN_ERR_STATE, "pn_train_pack_cache: a convolution met weights that were never packed while the stream is capturing (run one eager step first)");
+    pn_ctx::PackEntry e;
+    e.w = w; e.Cout = Cout; e.Cin = Cin; e.flip = flip; e.x3 = x3; e.bytes = bytes; e.fresh = true; e.buf = nullptr;
+    PN_HIP_CHECK(ctx, hipMalloc(&e.buf, bytes));
+    ctx->train_packs.push_back(e);
+    *buf = e.buf;
+    return PN_OK;
+}
+
 __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g, const __bf16 *__restrict__ wpx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char t_smem8[];
     unsigned char *As_hi = t_smem8, *As_lo = t_smem8 + TX_A_BYTES;          // [3 taps][64 couts][32 ch]
@@ -1320,22 +1371,6 @@ static void t_chan_reduce(hipStream_t s, const float *x, const float *dy, const 
         hipLaunchKernelGGL((chan_reduce_kernel<MODE, 1>), dim3((unsigned)C, (unsigned)slices), dim3(256), 0, s, x, dy, out, mean, invstd, gamma, beta, act, N, C, HW, slices, partial);
 }
 
-__global__ void bn_stats_finish_kernel(const double *__restrict__ partial, int C, int slices, double count, float eps, float momentum,
-                                       float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ running_mean,
-                                       float *__restrict__ running_var) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
-    const double mean = s / count;
-    double var = ss / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    save_mean[ch] = (float)mean;
-    save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
-    if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * (count / (count - 1.0)));
-}
-
 __global__ void sums_finish_kernel(const double *__restrict__ partial, int C, int slices, float *__restrict__ out0, float *__restrict__ out1,
                                    const float *__restrict__ invstd) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1346,28 +1381,32 @@ __global__ void sums_finish_kernel(const double *__restrict__ partial, int C, in
     if (out1) out1[ch] = (float)(invstd ? ss * (double)invstd[ch] : ss);   // d gamma = sum g (x - mean) * invstd
 }
 
-// BatchNorm backward: d beta = sum g, raw sum g (x - mean) for the apply kernel, d gamma = that * invstd -- one launch
-__global__ void bn_bwd_finish_kernel(const double *__restrict__ partial, int C, int slices, const float *__restrict__ invstd, float *__restrict__ dbeta,
-                                     float *__restrict__ sum_gx, float *__restrict__ dgamma) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
-    dbeta[ch] = (float)s;
-    sum_gx[ch] = (float)ss;
-    dgamma[ch] = (float)(ss * (double)invstd[ch]);
-}
-
 // V = 4: four consecutive pixels per thread as one 16-byte access (HW a multiple of 4: every map of the network); V = 1 otherwise
+// Round 4: the statistics are FINISHED here (bn_stats_finish_kernel's arithmetic, same order, in every thread of the block: `slices` <= 256
+// partial pairs of the block's channel) instead of in a launch of their own -- 33 launches of one 64-thread block each per training step less;
+// the block of image 0 / pixel group 0 publishes mean / invstd for the backward pass and updates the running statistics.
 template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ res, int act,
-                                int C, int HW, float *__restrict__ y) {
+                                const double *__restrict__ partial, int slices, double count, float eps, float momentum,
+                                float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                const float *__restrict__ res, int act, int C, int HW, float *__restrict__ y) {
     const int p = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-    if (p >= HW) return;
     const int ch = blockIdx.y % C;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    const double dmean = s / count;
+    double var = ss / count - dmean * dmean;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)dmean, is = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && (int)blockIdx.y == ch && threadIdx.x == 0) {
+        save_mean[ch] = mu;
+        save_invstd[ch] = is;
+        if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * dmean);
+        if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * (count / (count - 1.0)));
+    }
+    if (p >= HW) return;
     const size_t i = (size_t)blockIdx.y * HW + p;
-    const float mu = mean[ch], is = invstd[ch], ga = gamma[ch], be = beta[ch];
+    const float ga = gamma[ch], be = beta[ch];
     float xv[V], rv[V], o[V];
     if (V == 4) {
         *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + i);
@@ -1390,18 +1429,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
 
 // dx = gamma * invstd * (g - sum_g / n - (x - mean) * invstd^2 * sum_gx / n);  dres (+)= g   (identity path of a BasicBlock)
 // grid (ceil(HW / (256 V)), N * C): the channel is uniform per block, no division per element
+// Round 4: the two channel sums are finished here (bn_bwd_finish_kernel's arithmetic: slice-order double sums rounded to float) by every
+// thread of the block; the block of image 0 / pixel group 0 writes d beta and d gamma.
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ out,
                                     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                    const float *__restrict__ sum_g, const float *__restrict__ sum_gx, int act, int C, int HW, float inv_count,
+                                    const double *__restrict__ partial, int slices, float *__restrict__ dbeta, float *__restrict__ dgamma,
+                                    int act, int C, int HW, float inv_count,
                                     float *__restrict__ dx, float *__restrict__ dres, int dres_accumulate) {
     const int p = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-    if (p >= HW) return;
     const int ch = blockIdx.y % C;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    const float sum_g = (float)s, sum_gx = (float)ss;
+    if (blockIdx.x == 0 && (int)blockIdx.y == ch && threadIdx.x == 0) {
+        dbeta[ch] = sum_g;
+        dgamma[ch] = (float)(ss * (double)invstd[ch]);
+    }
+    if (p >= HW) return;
     const size_t i = (size_t)blockIdx.y * HW + p;
     const float is = invstd[ch], mu = mean[ch], ga = gamma[ch];
     const float be = (act != PN_ACT_NONE && !out) ? beta[ch] : 0.f;
-    const float mg = sum_g[ch] * inv_count, k2 = sum_gx[ch] * inv_count * is * is;
+    const float mg = sum_g * inv_count, k2 = sum_gx * inv_count * is * is;
     float xv[V], gv[V], ov[V], dv[V], rv[V];
     if (V == 4) {
         *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + i);
@@ -1575,6 +1624,52 @@ int pn_train_ws_keep(pn_ctx *ctx, int keep) {
     return PN_OK;
 }
 
+int pn_train_pack_cache(pn_ctx *ctx, int enable) {
+    T_CTX_CHECK("pn_train_pack_cache")
+    if (!enable && ctx->train_pack_cache) {
+        PN_HIP_CHECK(ctx, hipDeviceSynchronize());
+        for (auto &e : ctx->train_packs) (void)hipFree(e.buf);
+        ctx->train_packs.clear();
+        if (ctx->train_pack_table) (void)hipFree(ctx->train_pack_table);
+        ctx->train_pack_table = nullptr;
+        ctx->train_pack_table_entries = 0;
+    }
+    ctx->train_pack_cache = enable != 0;
+    return PN_OK;
+}
+
+int pn_train_pack_refresh(pn_ctx *ctx, void *hip_stream) {
+    T_CTX_CHECK("pn_train_pack_refresh")
+    if (!ctx->train_pack_cache || ctx->train_packs.empty()) return PN_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t n = ctx->train_packs.size();
+    if (ctx->train_pack_table_entries != n) {
+        // the list has grown since the table was uploaded (the engine's first steps): rebuild it -- never under a capture
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap != hipStreamCaptureStatusNone)
+            return pn_set_error(ctx, PN_ERR_STATE, "pn_train_pack_refresh: the pack list changed since the last eager step; run one eager step before capturing");
+        std::vector<TPackDesc> host(n);
+        unsigned blocks = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const auto &e = ctx->train_packs[i];
+            const size_t items = e.x3 ? (size_t)((e.Cin + 31) / 32) * 9 * e.Cout * 32 : (size_t)9 * e.Cin * e.Cout;
+            host[i] = TPackDesc{e.w, e.buf, e.Cout, e.Cin, e.flip, e.x3, blocks, 0u};
+            blocks += (unsigned)((items + 255) / 256);
+        }
+        PN_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        if (ctx->train_pack_table) (void)hipFree(ctx->train_pack_table);
+        PN_HIP_CHECK(ctx, hipMalloc(&ctx->train_pack_table, n * sizeof(TPackDesc)));
+        PN_HIP_CHECK(ctx, hipMemcpy(ctx->train_pack_table, host.data(), n * sizeof(TPackDesc), hipMemcpyHostToDevice));
+        ctx->train_pack_table_entries = n;
+        ctx->train_pack_blocks = blocks;
+    }
+    hipLaunchKernelGGL(wpack_all_kernel, dim3(ctx->train_pack_blocks), dim3(256), 0, s, (const TPackDesc *)ctx->train_pack_table, (int)n);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    for (auto &e : ctx->train_packs) e.fresh = true;
+    return PN_OK;
+}
+
 int pn_train_set_precision(pn_ctx *ctx, int precision) {
     T_CTX_CHECK("pn_train_set_precision")
     if (precision != PN_PREC_F32 && precision != PN_PREC_BF16X3)
@@ -1605,12 +1700,13 @@ int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const
         const size_t wn = (size_t)Cout * Cin * 9;
         const size_t wx = (size_t)((Cin + 31) / 32) * 9 * Cout * 32;        // elements per plane of the split-bf16 pack
         void *ws = nullptr;
-        int rc = t_ws(ctx, wn * sizeof(float) > 4 * wx ? wn * sizeof(float) : 4 * wx, &ws);
-        if (rc != PN_OK) return rc;
+        bool fresh = false;
+        int rc;
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
         TTile gx;
         if (ctx->train_x3 && Cin >= 32 && t_tile_geometry_x3(c.Ho, c.Wo, &gx)) {
-            hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cout, Cin, 0);
+            if ((rc = t_pack_get(ctx, w_dev, Cout, Cin, 0, 1, 4 * wx, s, &ws, &fresh)) != PN_OK) return rc;
+            if (!fresh) hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cout, Cin, 0);
             TTile gw2;
             if (!getenv("POPNET_TRAIN_X3_NARROW") && t_tile_geometry_x3w(c.Ho, c.Wo, N, Cout, &gw2)) {
                 const size_t ldsw2 = (size_t)2 * TXW2_A_BYTES + (size_t)2 * gw2.HR * gw2.HC * TXW2_PITCH;
@@ -1623,7 +1719,8 @@ int pn_conv2d_forward(pn_ctx *ctx, const float *x_dev, const float *w_dev, const
             PN_HIP_CHECK(ctx, hipGetLastError());
             return PN_OK;
         }
-        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, 0);
+        if ((rc = t_pack_get(ctx, w_dev, Cout, Cin, 0, 0, wn * sizeof(float), s, &ws, &fresh)) != PN_OK) return rc;
+        if (!fresh) hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, 0);
         const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
         hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cout + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
         PN_HIP_CHECK(ctx, hipGetLastError());
@@ -1646,8 +1743,8 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
     const size_t wn = (size_t)Cout * Cin * ks * ks;
     const size_t wx = (size_t)((Cout + 31) / 32) * 9 * Cin * 32;          // elements per plane of the split-bf16 pack (conv input channels = Cout)
     void *ws = nullptr;
-    int rc = t_ws(ctx, (ks == 3 && 4 * wx > wn * sizeof(float)) ? 4 * wx : wn * sizeof(float), &ws);
-    if (rc != PN_OK) return rc;
+    bool fresh = false;
+    int rc;
     hipStream_t s = (hipStream_t)hip_stream;
     TTile g;
     if (ks == 3 && Cout >= 16 && t_tile_geometry(H, W, 16, &g)) {
@@ -1659,7 +1756,8 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
         if ((rc = t_tile_lds_ok(ctx)) != PN_OK) return rc;
         TTile gx;
         if (ctx->train_x3 && Cout >= 32 && t_tile_geometry_x3(H, W, &gx)) {
-            hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cin, Cout, 1);
+            if ((rc = t_pack_get(ctx, w_dev, Cin, Cout, 1, 1, 4 * wx, s, &ws, &fresh)) != PN_OK) return rc;
+            if (!fresh) hipLaunchKernelGGL(wpack3_x3_kernel, dim3((unsigned)((wx + 255) / 256)), dim3(256), 0, s, w_dev, (__bf16 *)ws, Cin, Cout, 1);
             TTile gw2;
             if (!getenv("POPNET_TRAIN_X3_NARROW") && t_tile_geometry_x3w(H, W, N, Cin, &gw2)) {
                 const size_t ldsw2 = (size_t)2 * TXW2_A_BYTES + (size_t)2 * gw2.HR * gw2.HC * TXW2_PITCH;
@@ -1672,12 +1770,14 @@ int pn_conv2d_dgrad(pn_ctx *ctx, const float *dy_dev, const float *w_dev, float 
             PN_HIP_CHECK(ctx, hipGetLastError());
             return PN_OK;
         }
-        hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cin, Cout, 1);
+        if ((rc = t_pack_get(ctx, w_dev, Cin, Cout, 1, 0, wn * sizeof(float), s, &ws, &fresh)) != PN_OK) return rc;
+        if (!fresh) hipLaunchKernelGGL(wpack3_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cin, Cout, 1);
         const size_t lds = (size_t)(144 * TT_AP + 16 * g.CHP) * sizeof(float);
         hipLaunchKernelGGL(tconv3_tile_kernel, dim3((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)((Cin + 63) / 64)), dim3(256), lds, s, c, g, (const float *)ws);
         PN_HIP_CHECK(ctx, hipGetLastError());
         return PN_OK;
     }
+    if ((rc = t_ws(ctx, wn * sizeof(float), &ws)) != PN_OK) return rc;
     hipLaunchKernelGGL(wflip_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, w_dev, (float *)ws, Cout, Cin, ks);
     // dX = conv(dY [N, Cout, Ho, Wo], Wt [Cin, Cout, ks, ks], padding ks - 1 - pad)
     return pn_conv2d_forward(ctx, dy_dev, (const float *)ws, nullptr, dx_dev, N, Cout, Ho, Wo, Cin, ks, 1, ks - 1 - pad, accumulate, hip_stream);
@@ -1803,16 +1903,14 @@ int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev,
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     t_chan_reduce<0>(s, x_dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, C, HW, sl, (double *)ws);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, (double)cnt, eps, momentum,
-                       save_mean_dev, save_invstd_dev, running_mean_dev, running_var_dev);
     if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_forward: N * C out of range");
     const bool v4 = (HW & 3) == 0 && ((((size_t)x_dev) | ((size_t)y_dev) | ((size_t)res_dev)) & 15) == 0;
     if (v4)
-        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev,
-                           save_invstd_dev, res_dev, act, C, HW, y_dev);
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, (const double *)ws, sl,
+                           (double)cnt, eps, momentum, save_mean_dev, save_invstd_dev, running_mean_dev, running_var_dev, res_dev, act, C, HW, y_dev);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, save_mean_dev,
-                           save_invstd_dev, res_dev, act, C, HW, y_dev);
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, gamma_dev, beta_dev, (const double *)ws, sl,
+                           (double)cnt, eps, momentum, save_mean_dev, save_invstd_dev, running_mean_dev, running_var_dev, res_dev, act, C, HW, y_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -1826,21 +1924,19 @@ int pn_bn_train_backward(pn_ctx *ctx, const float *x_dev, const float *dy_dev, c
     const long cnt = (long)N * HW;
     const int sl = t_slices(cnt, C);
     void *ws = nullptr;
-    int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double) + (size_t)C * sizeof(float), &ws);
+    int rc = t_ws(ctx, (size_t)C * sl * 2 * sizeof(double), &ws);
     if (rc != PN_OK) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     t_chan_reduce<1>(s, x_dev, dy_dev, out_dev, save_mean_dev, save_invstd_dev, gamma_dev, beta_dev, act, N, C, HW, sl, (double *)ws);
-    // d beta = sum g, sum g (x - mean) (raw, into the scratch) and d gamma = that * invstd
-    float *sgx = (float *)((char *)ws + (size_t)C * sl * 2 * sizeof(double));
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, (const double *)ws, C, sl, save_invstd_dev, dbeta_dev, sgx, dgamma_dev);
+    // d beta = sum g, d gamma = sum g (x - mean) * invstd: finished inside the apply kernel
     if ((long)N * C > 65535) return pn_set_error(ctx, PN_ERR_INVALID, "pn_bn_train_backward: N * C out of range");
     const bool v4 = (HW & 3) == 0 && ((((size_t)x_dev) | ((size_t)dy_dev) | ((size_t)out_dev) | ((size_t)dx_dev) | ((size_t)dres_dev)) & 15) == 0;
     if (v4)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, beta_dev,
-                           save_mean_dev, save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
+                           save_mean_dev, save_invstd_dev, (const double *)ws, sl, dbeta_dev, dgamma_dev, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3((unsigned)((HW + 255) / 256), (unsigned)(N * C)), dim3(256), 0, s, x_dev, dy_dev, out_dev, gamma_dev, beta_dev,
-                           save_mean_dev, save_invstd_dev, (const float *)dbeta_dev, (const float *)sgx, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
+                           save_mean_dev, save_invstd_dev, (const double *)ws, sl, dbeta_dev, dgamma_dev, act, C, HW, (float)(1.0 / (double)cnt), dx_dev, dres_dev, dres_accumulate);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -1907,6 +2003,7 @@ int pn_sgd_nesterov(pn_ctx *ctx, float *param_dev, const float *grad_dev, float 
     T_CTX_CHECK("pn_sgd_nesterov")
     if (!param_dev || !grad_dev || !momentum_buf_dev) return pn_set_error(ctx, PN_ERR_INVALID, "pn_sgd_nesterov: bad arguments");
     if (n == 0) return PN_OK;
+    for (auto &e : ctx->train_packs) e.fresh = false;         // the weights move: cached packs are stale until the next pn_train_pack_refresh (or per-call pack)
     hipLaunchKernelGGL(sgd_nesterov_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, param_dev, grad_dev, momentum_buf_dev, n,
                        lr, momentum, weight_decay, first_step, grad_scale);
     PN_HIP_CHECK(ctx, hipGetLastError());

@@ -43,6 +43,8 @@ class TrainEngine:
             raise ValueError("precision must be 'fp32' or 'bf16x3', got %r" % (precision,))
         self.precision = precision
         self.ctx.check(self.L.pn_train_set_precision(self.ctx.handle, _lib.PN_PREC_BF16X3 if precision == "bf16x3" else 0), "pn_train_set_precision")
+        # packed conv weights cached in the (private) context and refreshed by ONE launch at the start of every step (forward_backward)
+        self.ctx.check(self.L.pn_train_pack_cache(self.ctx.handle, 1), "pn_train_pack_cache")
         self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
         self.group, self.world = process_group, int(world_size)
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
@@ -226,6 +228,7 @@ class TrainEngine:
             raise _lib.PopnetError("popnet_amd.train: fg_mask must be [%d, 15, %d, %d]" % (N, h, w))
         self.A = {}
         L, ctx, s = self.L, self.ctx.handle, self._s()
+        self._check(L.pn_train_pack_refresh(ctx, s), "pn_train_pack_refresh")       # every cached weight pack, one launch (whatever changed the weights)
         # forward (rtpose_light3d.py:206-219, 328-354)
         a = self._bn("model0.bn1", self._conv("model0.conv1", img, 7, 2, 3), ACT_RELU)
         a = self._block("model0.layer1.1", self._block("model0.layer1.0", a))
@@ -326,6 +329,10 @@ class TrainEngine:
             raise _lib.PopnetError("popnet_amd.train: capture(warmup_steps=0) needs an engine that has already taken a step")
         for _ in range(warmup_steps):
             self.step(*batch)
+        torch.cuda.synchronize(self.device)
+        # the pack cache's descriptor table is (re)built by an eager refresh -- never under a capture: bring it up to date now (a step run
+        # before this call may have added entries after its own refresh)
+        self._check(self.L.pn_train_pack_refresh(self.ctx.handle, self._s()), "pn_train_pack_refresh")
         torch.cuda.synchronize(self.device)
         self._static = [t.clone() for t in batch]
         # the graph will point into the context's scratch: a later, larger eager step must retire that block, not free it

@@ -539,6 +539,28 @@ def test_captured_training_step_equals_eager(gpu, golden):
     assert torch.equal(eager.flat_p, graph.flat_p) and torch.equal(eager.flat_m, graph.flat_m)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_weight_pack_cache_equals_per_call_packs(gpu, golden, prec):
+    """Round 4: the packed weights of the 3x3 training convolutions are cached in the engine's context and refreshed by
+    ONE launch per step (pn_train_pack_refresh) instead of one pack launch per convolution call.  Same pack arithmetic: an engine with the
+    cache and one without (pn_train_pack_cache(ctx, 0)) hold bit-identical parameters, momentum and statistics after four steps -- also when
+    a weight is changed BEHIND the optimiser's back between two steps (the refresh at the start of a step repacks everything)."""
+    from popnet_amd.train import TrainEngine
+    sd = init_like_state_dict(golden.keys["rtpose_light3d"], seed=8)
+    batches = [[torch.from_numpy(a).to(gpu) for a in train_case_inputs(seed=700 + i, B=2, H=64, W=96)] for i in range(4)]
+    cached, plain = TrainEngine(sd, device=gpu, lr=0.05, precision=prec), TrainEngine(sd, device=gpu, lr=0.05, precision=prec)
+    plain.ctx.check(plain.L.pn_train_pack_cache(plain.ctx.handle, 0), "pn_train_pack_cache")
+    for i, b in enumerate(batches):
+        if i == 2:                                    # an out-of-band edit of a 3x3 weight: both engines must see it in the next step
+            for e in (cached, plain):
+                e.p["model1_1.3.weight"].mul_(1.25)
+        assert torch.equal(cached.step(*b).clone(), plain.step(*b).clone()), i
+    torch.cuda.synchronize()
+    assert torch.equal(cached.flat_p, plain.flat_p) and torch.equal(cached.flat_m, plain.flat_m)
+    a, b2 = cached.state_dict(), plain.state_dict()
+    assert all(torch.equal(a[k].cpu(), b2[k].cpu()) for k in a)
+
+
 def test_synthetic_train_eval_script_runs(gpu, capsys, monkeypatch):
     """scripts/synthetic_train_eval.py (train on synthetic scenes -> checkpoint -> inference engines -> metrics) at a toy length:
     the plumbing between compositor, target rasteriser, captured training step, state_dict, PoseEngine and metrics holds and the
