@@ -203,6 +203,40 @@ def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, mo
     assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y), switch
 
 
+@pytest.mark.parametrize("hw,B", [((224, 224), 3), ((200, 232), 2), ((256, 192), 2)])
+def test_bf16x3_strip_kernels_equal_the_generic_kernel_bit_for_bit(gpu, golden, hw, B, monkeypatch):
+    """The tolerance-meeting mode on the strip kernels (conv3_kernel, conv4_kernel where a level has >= 448 blocks or everywhere with
+    POPNET_CONV4=1) against the generic kernel on every layer (POPNET_NO_CONV3=1), under
+    precision="bf16x3" with two-plane tensors [hi | lo] whose third plane pair re-reads hi (ConvProblem::in_wrap): same k order, same MFMA,
+    same epilogue arithmetic -> IDENTICAL maps, both networks, ragged maps included."""
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    H, W = hw
+    x = torch.from_numpy(np.random.default_rng(46).normal(0, 1, (B, 1, H, W)).astype(np.float32)).to(gpu)
+
+    def yolo():
+        m = YoloPoseNet(15, input_dim=1).eval()
+        m.load_state_dict(state_dict_from_keys(golden.keys["yolo_posenet"], seed=1))
+        m.precision = "bf16x3"
+        return m
+
+    do_yolo = H % 16 == 0 and W % 16 == 0
+    got = [t.clone() for t in _rtpose(golden, "bf16x3")(x)[0]]
+    got_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.setenv("POPNET_CONV4", "1")
+    got4 = [t.clone() for t in _rtpose(golden, "bf16x3")(x)[0]]
+    monkeypatch.delenv("POPNET_CONV4")
+    monkeypatch.setenv("POPNET_NO_CONV3", "1")          # read when the net is compiled
+    ref = [t.clone() for t in _rtpose(golden, "bf16x3")(x)[0]]
+    ref_y = yolo()(x).clone() if do_yolo else None
+    monkeypatch.delenv("POPNET_NO_CONV3")
+    torch.cuda.synchronize()
+    for a, a4, b, name in zip(got, got4, ref, ("paf", "heat", "z")):
+        assert torch.isfinite(a).all() and torch.equal(a, b), name
+        assert torch.equal(a4, b), ("conv4", name)
+    if do_yolo:
+        assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y)
+
+
 @pytest.mark.parametrize("hw,B", [((224, 224), 5), ((200, 232), 3), ((256, 192), 2), ((96, 480), 3), ((72, 136), 4)])
 def test_bf16x3_fused_basic_block_equals_the_two_launch_plan_bit_for_bit(gpu, golden, hw, B, monkeypatch):
     """bb64x3_kernel: the BasicBlock(64)s of the split-bf16 nets as ONE launch -- two-plane LDS images, the
