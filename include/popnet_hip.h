@@ -81,7 +81,9 @@ int pn_preprocess(pn_ctx *ctx, const void *depth_dev, int depth_dtype, int B, in
  *   (tpm/evaluate/evaluation_rtpose_light3d_kdh3d_mpreal_ablation.py:135-144)
  * and the YoloPoseNet twin (tpm/evaluate/evaluation_yolo_posenet_kdh3d_mpreal.py:119-128).
  * Tensor names are the reference state_dict keys, without "module.".
- * `a` = num_limbs for rtpose_light3d, number of anchors for YoloPoseNet.                        */
+ * `a` = num_limbs for rtpose_light3d, number of anchors for YoloPoseNet.  input_dim = channels of the input batch [B, input_dim, H, W]
+ * (1 = depth, the path north_star names: fused matrix-core stem, frames-in forward; 2..16, e.g. the reference constructors' default 3
+ * (rtpose_light3d.py:250, yolo_posenet.py:88): the 7x7 stem on the generic fp32 convolution, pn_*_forward only).                          */
 pn_net *pn_net_create(pn_ctx *ctx, int kind, int num_parts, int a, int input_dim);
 void pn_net_destroy(pn_net *net);
 /* Host fp32 data, copied.  Unknown names are rejected, except keys the reference builds but

@@ -480,3 +480,37 @@ int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, in
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// NCHW f32 -> ReLU -> NHWC T channel slice (bf16x3: two planes [hi | lo] `split` channels apart).  The multi-channel stem
+// (input_dim != 1: the reference constructors' default is input_dim = 3, tpm/lib/network/rtpose_light3d.py:250, yolo_posenet.py:88)
+// runs the generic fp32 7x7 convolution of the training primitives (pn_conv2d_forward, any Cin) and hands its map to the NHWC
+// layers through this kernel.  Not on the depth path's timed region (north_star: single-channel depth).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_relu_to_nhwc_kernel(const float *__restrict__ in, T *__restrict__ out, int B, int HW, int C, int out_cs, int split) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // gid = (b * HW + p) * C + ch: consecutive threads write consecutive channels
+    size_t total = (size_t)B * C * HW;
+    if (gid >= total) return;
+    int ch = (int)(gid % C);
+    size_t t = gid / C;
+    int p = (int)(t % HW);
+    int b = (int)(t / HW);
+    float v = in[((size_t)b * C + ch) * HW + p];
+    v = v > 0.f ? v : 0.f;
+    T *op = out + ((size_t)b * HW + p) * out_cs + ch;
+    const T hi = (T)v;
+    op[0] = hi;
+    if (split) op[split] = (T)(v - (float)hi);
+}
+
+int pn_launch_nchw_relu_to_nhwc(pn_ctx *ctx, int prec, const float *in, void *out, int B, int H, int W, int C, int out_cs, int split, hipStream_t stream) {
+    size_t total = (size_t)B * C * H * W;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (prec == PN_PREC_BF16)
+        hipLaunchKernelGGL(nchw_relu_to_nhwc_kernel<__bf16>, grid, block, 0, stream, in, (__bf16 *)out, B, H * W, C, out_cs, split);
+    else
+        hipLaunchKernelGGL(nchw_relu_to_nhwc_kernel<float>, grid, block, 0, stream, in, (float *)out, B, H * W, C, out_cs, 0);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}

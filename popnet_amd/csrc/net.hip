@@ -76,6 +76,8 @@ struct Step {
     int stem_pool_buf = -1;          // >= 0: the MaxPool2d(3, 2, 1) that follows runs inside the stem launch and writes this buffer (build_yolo)
     float *stem_w = nullptr, *stem_b = nullptr;
     void *stem_wfrag = nullptr;      // bf16 MFMA fragments of the same weights
+    int stem_cin = 1;                // > 1: multi-channel input (input_dim != 1): stem_w = folded [64][Cin][7][7] f32 for pn_conv2d_forward, stem_scratch = its NCHW f32 map
+    float *stem_scratch = nullptr;
     // POOL
     int mode = 0, in_buf = -1, C = 0, out_coff = 0;
     // CONV: indices into pn_net::convs, all sharing one kernel instantiation
@@ -484,11 +486,36 @@ void add_pool(pn_net *n, int mode, int in_buf, int out_buf, int C, int out_coff)
 int add_stem(pn_net *n, int out_buf) {
     pn_ctx *ctx = n->ctx;
     const HostTensor *w = find_t(n, "model0.conv1.weight");
-    if (!w || w->shape.size() != 4 || w->shape[0] != 64 || w->shape[1] != 1 || w->shape[2] != 7)
-        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "model0.conv1.weight must be [64,1,7,7] (single-channel depth input)");
+    if (!w || w->shape.size() != 4 || w->shape[0] != 64 || w->shape[1] != n->input_dim || w->shape[2] != 7 || w->shape[3] != 7)
+        return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "model0.conv1.weight must be [64,%d,7,7] (input_dim = %d)", n->input_dim, n->input_dim);
     const HostTensor *g = find_t(n, "model0.bn1.weight"), *be = find_t(n, "model0.bn1.bias");
     const HostTensor *mu = find_t(n, "model0.bn1.running_mean"), *var = find_t(n, "model0.bn1.running_var");
     if (!g || !be || !mu || !var) return pn_set_error(ctx, PN_ERR_INVALID, "missing model0.bn1.*");
+    if (n->input_dim != 1) {
+        // multi-channel input (the reference constructors default to input_dim = 3, rtpose_light3d.py:250 / yolo_posenet.py:88): the folded
+        // 7x7 convolution runs on the generic fp32 primitive (pn_conv2d_forward, any Cin), its NCHW map is handed to the NHWC layers by
+        // nchw_relu_to_nhwc_kernel.  The depth path (input_dim = 1) keeps its fused matrix-core stem.
+        const int cin = n->input_dim;
+        std::vector<float> hw((size_t)64 * cin * 49), hb(64);
+        for (int o = 0; o < 64; ++o) {
+            const double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+            for (int i = 0; i < cin * 49; ++i) hw[(size_t)o * cin * 49 + i] = (float)((double)w->data[(size_t)o * cin * 49 + i] * s);
+            hb[o] = (float)((0.0 - (double)mu->data[o]) * s + (double)be->data[o]);
+        }
+        Step st;
+        st.type = Step::STEM;
+        st.out_buf = out_buf;
+        st.stem_cin = cin;
+        if (int rc = dev_alloc(n, (void **)&st.stem_w, hw.size() * 4, false)) return rc;
+        if (int rc = dev_alloc(n, (void **)&st.stem_b, hb.size() * 4, false)) return rc;
+        PN_HIP_CHECK(ctx, hipMemcpy(st.stem_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        PN_HIP_CHECK(ctx, hipMemcpy(st.stem_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+        const Buf &ob = n->bufs[out_buf];
+        if (int rc = dev_alloc(n, (void **)&st.stem_scratch, (size_t)n->max_batch * 64 * ob.H * ob.W * 4, false)) return rc;
+        n->steps.push_back(st);
+        n->flops_per_frame += 2.0 * ob.H * ob.W * 64.0 * 49.0 * cin;
+        return PN_OK;
+    }
     std::vector<float> hw(49 * 64), hb(64);
     for (int o = 0; o < 64; ++o) {
         double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
@@ -846,7 +873,7 @@ int build_yolo(pn_net *n) {
     auto level = [&](std::vector<int> ids) { levels.push_back(ids); };
     // conv1 - bn1 - relu - maxpool (yolo_posenet.py:101-108): one launch in bf16 (conv_misc.hip::stem7x7_pool_kernel; the 112 x 112 x 64
     // map is never stored); POPNET_NO_STEMPOOL=1, fp32 and bf16x3 keep the stem and the pool as two launches
-    if (n->prec == PN_PREC_BF16 && !n->x3 && !getenv("POPNET_NO_STEMPOOL")) n->steps.back().stem_pool_buf = X0;
+    if (n->prec == PN_PREC_BF16 && !n->x3 && n->input_dim == 1 && !getenv("POPNET_NO_STEMPOOL")) n->steps.back().stem_pool_buf = X0;
     else levels.push_back({-1, 1, A1, X0, 64, 0});   // maxpool 3x3 s2
     int cur = X0, other = X1;
     for (int i = 0; i < 3; ++i) {
@@ -1042,6 +1069,11 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         if (st.type == Step::STEM && st.stem_pool_buf >= 0) {
             const Buf &ob = n->bufs[st.out_buf], &pb = n->bufs[st.stem_pool_buf];
             rc = pn_launch_stem_pool(ctx, x, st.stem_wfrag, st.stem_b, pb.p, B, n->in_h, n->in_w, ob.H, ob.W, pb.C, stream, n->frame_src.frames ? &n->frame_src : nullptr);
+        } else if (st.type == Step::STEM && st.stem_cin > 1) {
+            const Buf &ob = n->bufs[st.out_buf];
+            if (n->frame_src.frames) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "the frames-in forward takes single-channel depth frames (input_dim = 1)");
+            rc = pn_conv2d_forward(ctx, x, st.stem_w, st.stem_b, st.stem_scratch, B, st.stem_cin, n->in_h, n->in_w, 64, 7, 2, 3, 0, (void *)stream);
+            if (!rc) rc = pn_launch_nchw_relu_to_nhwc(ctx, n->prec, st.stem_scratch, ob.p, B, ob.H, ob.W, 64, ob.C, n->x3 ? ob.plane : 0, stream);
         } else if (st.type == Step::STEM) {
             const Buf &ob = n->bufs[st.out_buf];
             rc = pn_launch_stem(ctx, n->x3 ? PN_PREC_BF16X3 : n->prec, x, st.stem_w, st.stem_wfrag, st.stem_b, ob.p, B, n->in_h, n->in_w, ob.H, ob.W, ob.C, n->x3 ? ob.plane : 0, stream,
@@ -1083,8 +1115,8 @@ pn_net *pn_net_create(pn_ctx *ctx, int kind, int num_parts, int a, int input_dim
         pn_set_error(ctx, PN_ERR_INVALID, "unknown net kind %d", kind);
         return nullptr;
     }
-    if (input_dim != 1) {
-        pn_set_error(ctx, PN_ERR_UNSUPPORTED, "only single-channel depth input (input_dim=1) is built");
+    if (input_dim < 1 || input_dim > 16) {
+        pn_set_error(ctx, PN_ERR_UNSUPPORTED, "input_dim %d outside [1, 16]", input_dim);
         return nullptr;
     }
     pn_net *n = new pn_net();

@@ -177,6 +177,8 @@ int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const 
 int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, int B, int H, int W,
                    int C, int in_cs, int out_cs, int out_coff, int in_split, int out_split, hipStream_t stream);
 
+// NCHW f32 -> ReLU -> NHWC T (the multi-channel stem's hand-over, conv_misc.hip)
+int pn_launch_nchw_relu_to_nhwc(pn_ctx *ctx, int prec, const float *in, void *out, int B, int H, int W, int C, int out_cs, int split, hipStream_t stream);
 // NHWC T channel slice -> NCHW f32 (diagnostics / stage-1 outputs).
 int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, int B, int H, int W,
                            int C, int in_cs, int in_coff, int split, hipStream_t stream);

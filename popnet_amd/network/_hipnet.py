@@ -131,8 +131,9 @@ class HipNetModule(nn.Module):
 
     def _check_input(self, x):
         _lib.require_cuda_tensor(x, "input")
-        if x.dim() != 4 or x.shape[1] != 1:
-            raise _lib.PopnetError("expected a [B,1,H,W] depth batch, got %s" % (tuple(x.shape),))
+        cin = int(getattr(self, "input_dim", 1))
+        if x.dim() != 4 or x.shape[1] != cin:
+            raise _lib.PopnetError("expected a [B,%d,H,W] batch (input_dim = %d), got %s" % (cin, cin, tuple(x.shape)))
         return x.contiguous().float()
 
     def _activation(self, name, B, shape, device):

@@ -136,6 +136,50 @@ def test_forward_other_input_sizes(gpu, golden):
         assert (got.cpu() - ref).abs().max() < 2e-4
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16x3", 5e-4), ("bf16", 0.15)])
+def test_multi_channel_input_vs_oracle(gpu, golden, prec, tol):
+    """input_dim != 1 (round 4; the reference constructors DEFAULT to input_dim = 3: rtpose_light3d.py:250, yolo_posenet.py:88): the 7x7 stem
+    of a 3-channel input runs on the generic fp32 convolution primitive and hands its map to the NHWC layers; both networks, every precision
+    mode, against the oracle's torch fp32 forward of the same state_dict (same tolerances as the single-channel tests).  A batch whose channel
+    count does not match input_dim is refused."""
+    from oracle import nets
+    from popnet_amd.network.rtpose_light3d import rtpose_light3d
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    x = torch.from_numpy(np.random.default_rng(56).normal(0, 1, (3, 3, 224, 224)).astype(np.float32))
+
+    def widen(keys, seed):            # the golden key list with a 3-channel stem
+        keys = [[k, ([64, 3, 7, 7] if k == "model0.conv1.weight" else s)] for k, s in keys]
+        return state_dict_from_keys(keys, seed=seed)
+
+    sd = widen(golden.keys["rtpose_light3d"], 0)
+    m = rtpose_light3d(15, 14, 2).eval()               # input_dim = 3: the reference's default
+    assert m.input_dim == 3
+    m.load_state_dict(sd)
+    m.precision = prec
+    (p, h, z), _ = m(x.to(gpu))
+    torch.cuda.synchronize()
+    for got, ref, name in zip((p, h, z), nets.rtpose_light3d_forward(x, sd), ("paf", "heat", "z")):
+        d = (got.cpu() - ref).abs()
+        assert torch.isfinite(got).all() and float(d.max()) < tol, (name, float(d.max()))
+    with pytest.raises(_lib.PopnetError, match="input_dim"):
+        m(x[:, :1].to(gpu))
+    sdy = widen(golden.keys["yolo_posenet"], 1)
+    my = YoloPoseNet(15).eval()
+    my.load_state_dict(sdy)
+    my.precision = prec
+    out = my(x.to(gpu))
+    torch.cuda.synchronize()
+    ref = nets.yolo_posenet_forward(x, sdy)
+    d = (out.cpu() - ref).abs()
+    # the single-channel Yolo tests' tolerances (activations reach |x| ~ 150 with these weights); plain bf16 flips saturated sigmoid casts
+    # outright (range [-2, 2]): bounded in the mean, as the bf16 rtpose maps are
+    assert torch.isfinite(out).all()
+    if prec == "bf16":
+        assert float(d.mean()) < 0.05, float(d.mean())
+    else:
+        assert float(d.max()) < {"fp32": 2e-3, "bf16x3": 5e-3}[prec], float(d.max())
+
+
 @pytest.mark.parametrize("hw", [(224, 224), (240, 320), (200, 232), (256, 192), (96, 480)])
 def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, monkeypatch):
     """conv3_kernel (24..30-column strip tiles, partial last tiles, merged narrow convs) accumulates in the same k order
