@@ -39,7 +39,28 @@ class HipNetModule(nn.Module):
         raise NotImplementedError
 
     def _weights_version(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """(data_ptr, _version) of every parameter and buffer: changes when torch code re-assigns or writes a tensor in place.  The list of
+        (owner, name) slots is collected once (the module tree of these parameter holders is static), so the per-forward cost is one pass over
+        ~200 dictionary lookups, not a walk of the module tree; a tensor that is re-assigned or re-created (.cuda() / .to()) is
+        looked up afresh every time.
+        Writers that go through raw device pointers (the HIP training primitives updating BatchNorm running statistics, a TrainEngine
+        writing into module buffers) do NOT bump `_version`: they must call invalidate() -- `_forward_train` does."""
+        slots = self.__dict__.get("_version_tensors")
+        if slots is None:                      # (owner dict, name) of every parameter / buffer slot: a RE-ASSIGNED tensor is still seen
+            slots = []
+            for mod in self.modules():
+                slots += [(mod._parameters, k) for k, v in mod._parameters.items() if v is not None]
+                slots += [(mod._buffers, k) for k, v in mod._buffers.items() if v is not None]
+            self.__dict__["_version_tensors"] = slots
+        out = []
+        for d, k in slots:
+            t = d[k]
+            out.append((t.data_ptr(), t._version))
+        return tuple(out)
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop("_version_tensors", None)
+        return super()._apply(fn, *a, **kw)
 
     def _release(self):
         """Drops the compiled net.  A handle an engine holds locked (PoseEngine.lock / StreamingEngine.capture: captured hipGraphs
@@ -86,6 +107,7 @@ class HipNetModule(nn.Module):
         if state_dict and all(k.startswith("module.") for k in state_dict):
             state_dict = type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
         out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.__dict__.pop("_version_tensors", None)
         self.invalidate()
         return out
 
