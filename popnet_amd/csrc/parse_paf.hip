@@ -365,6 +365,13 @@ __global__ __launch_bounds__(256) void group_readout_kernel(const float *__restr
         static_assert(sizeof(ParseWs) % 8 == 0, "staged in 8-byte pieces");
         const uint2 *src = reinterpret_cast<const uint2 *>(&ws[b]);
         for (int i = tid; i < (int)(sizeof(ParseWs) / 8); i += 256) reinterpret_cast<uint2 *>(s_ws)[i] = src[i];
+        // rows beyond n_peaks / n_persons are never written below: the record starts as zeros, so that it is a pure function of its frame
+        // (bit-identical wherever in a batch, and in whatever buffer, the frame was processed).  Round 4: zeroed HERE, by the block that owns
+        // the record (the barrier below drains these stores -- vmcnt(0) -- before any thread writes a result), instead of by a 1 MB memset
+        // launch in front of the three parse kernels.
+        static_assert(sizeof(pn_pose_frame) % 16 == 0, "zeroed in 16-byte pieces");
+        uint4 *fz = reinterpret_cast<uint4 *>(&frames[b]);
+        for (int i = tid; i < (int)(sizeof(pn_pose_frame) / 16); i += 256) fz[i] = uint4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
     const ParseWs &W = *reinterpret_cast<const ParseWs *>(s_ws);
@@ -600,9 +607,7 @@ extern "C" int pn_parse_paf_wire(pn_ctx *ctx, const float *heat_dev, const float
     for (int p = 0; p < 8; ++p) host_cubic_coeffs((float)(2 * p + 1) / 16.0f, tab.c[p]);
     hipStream_t s = (hipStream_t)hip_stream;
     ParseWs *ws = (ParseWs *)ctx->parse_ws;
-    // rows beyond n_peaks / n_persons are not written by the kernels: zero them, so that a record is a pure function of
-    // its frame (bit-identical wherever in a batch, and in whatever buffer, the frame was processed)
-    PN_HIP_CHECK(ctx, hipMemsetAsync(frames_dev, 0, (size_t)B * sizeof(pn_pose_frame), s));
+    // (rows beyond n_peaks / n_persons read as zero: group_readout_kernel zeroes its own record first)
     hipLaunchKernelGGL(peaks_refine_kernel, dim3(J_, B), dim3(256), 0, s, heat_dev, h, w, J_ + 1, cfg->thresh_heatmap, tab, ws);
     hipLaunchKernelGGL(limb_match_kernel, dim3(L_, B), dim3(256), 0, s, paf_dev, h, w, 2 * L_, cfg->thresh_paf,
                        h * cfg->downsample, tab, ws);
