@@ -262,6 +262,51 @@ def bench_env():
     return env
 
 
+def surface_in_parsed(out):
+    """The driver's record keeps `config`, `roofline` and `cpu_baseline` of the line verbatim and lists every other key by name only
+    (VERDICT r04 items 1, 4).  What a reader of that record must see next to `value` therefore goes INTO those objects: whether the
+    headline dtype meets north_star's tolerance, the H2D-inclusive rate of the same region (SURVEY 8(d)'s literal metric), and the
+    tolerance-meeting mode's own throughput / fidelity -- nested once and repeated as flat scalars."""
+    cfg, rf = out["config"], out["roofline"]
+    h2d = out.get("h2d_inclusive") or {}
+    fid = out.get("fidelity") or {}
+    if h2d:
+        cfg["h2d_inclusive_value"] = h2d["value"]
+        cfg["h2d_inclusive_fraction_of_value"] = h2d["fraction_of_value"]
+        cfg["host_link_GBps"] = (h2d.get("host_link") or {}).get("GBps")
+    if fid:
+        cfg["value_meets_north_star_tolerance"] = fid["meets_north_star_tolerance"]
+        cfg["value_same_assignment"] = fid["same_assignment"]
+        cfg["value_d3_m_max"] = fid["d3_m_max"]
+    pm = out.get("parity_mode") or {}
+    if "value" in pm:
+        f = pm["fidelity"]["threshold_calibrated_weights"]
+        prf = pm["roofline"]
+        block = {"dtype": pm["dtype"], "value": pm["value"], "unit": "frames/s", "ms_per_step": pm["ms_per_step"],
+                 "h2d_inclusive": (pm.get("h2d_inclusive") or {}).get("value"),
+                 "frac_physical": prf["frac"], "frac_algorithmic": round(prf["algorithmic_tflops"] / prf["peak"], 4),
+                 "conv_stack_frac_physical": prf["conv_stack_physical_frac"],
+                 "same_assignment": "%d/%d" % (f["same_assignment"], f["frames"]), "d3_m_max": f["d3_m_max"],
+                 "meets_north_star_tolerance": bool(f["d3_m_max"] < 1e-3 and f["same_assignment"] >= f["frames"] - 2)}
+        rf["parity_mode"] = block
+        cfg["parity_mode"] = dict(block)
+        for k in ("value", "ms_per_step", "h2d_inclusive", "frac_physical", "same_assignment", "d3_m_max", "meets_north_star_tolerance"):
+            cfg["parity_mode_" + k] = block[k]
+    tr = out.get("train_step") or {}
+    if "ms_per_step" in tr:
+        cfg["train_step_ms_fp32"] = tr["ms_per_step"]
+        cfg["train_step_ms_bf16x3"] = (tr.get("bf16x3") or {}).get("ms_per_step")
+    yl = out.get("yolo") or {}
+    if "value" in yl:
+        cfg["yolo_value"] = yl["value"]
+        cfg["yolo_conv_stack_frac"] = (yl.get("conv_stack") or {}).get("frac")
+    cs = rf.get("conv_stack") or {}
+    rf["conv_stack_frac"] = cs.get("frac")
+    pp = out.get("postproc") or {}
+    if pp:
+        rf["postproc_us_per_step"] = pp.get("us_per_step")
+
+
 def plan_legs(world, rank, net, precision, no_extras, no_cpu_baseline):
     """Which secondary legs a rank runs besides the timed regions.  Everything here is rank-0-only AND world-1-only: an N-rank run
     (the driver's SCALE pass) times the headline region on every rank and nothing else -- no child processes, no CPU baseline, no
@@ -308,10 +353,20 @@ def dist_check(dev, world, rank, dist):
     g = torch.Generator(device="cpu").manual_seed(11)
     allrec = torch.randint(0, 256, (n_frames, item), dtype=torch.uint8, generator=g)
     mine = allrec[rank::world].to(dev)
-    t0 = time.perf_counter()
-    got = gather_records(mine, n_frames, rank, world)
+    # the first collective of a process group creates the communicator (178 ms at world 1 in round 4: that was what `gather_ms` timed);
+    # one warm-up exchange first, then the median of 5 timed gathers
+    ranks = torch.zeros(world, dtype=torch.int64, device=dev)
+    ranks[rank] = 1
+    dist.all_reduce(ranks)                                           # every rank adds its own 1: ranks_seen must equal world
+    gather_records(mine, n_frames, rank, world)
     sync()
-    t_gather = time.perf_counter() - t0
+    tg = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        got = gather_records(mine, n_frames, rank, world)
+        sync()
+        tg.append(time.perf_counter() - t0)
+    t_gather = float(np.median(tg))
     gather_ok = bool(torch.equal(got.cpu(), allrec))
     flat = torch.randn(5525816, generator=g).to(dev)               # the trainer's flat gradient buffer: 22 MB
     ref = flat.clone()
@@ -330,7 +385,8 @@ def dist_check(dev, world, rank, dist):
     maps = open("/proc/self/maps").read()
     libs = sorted({ln.split("/")[-1] for ln in maps.splitlines() if "librccl" in ln or "libnccl" in ln})
     return {"backend": dist.get_backend(), "world_size": world, "gather_records_ok": gather_ok, "flat_gradient_allreduce_ok": allreduce_ok,
-            "gather_ms": round(t_gather * 1e3, 3), "allreduce_22MB_ms": round(t_ar * 1e3, 3), "collective_library_loaded": libs,
+            "ranks_seen": int(ranks.sum().item()),
+            "gather_ms": round(t_gather * 1e3, 3), "gather_ms_what": "median of 5 gathers after one warm-up exchange (communicator creation excluded)", "allreduce_22MB_ms": round(t_ar * 1e3, 3), "collective_library_loaded": libs,
             "what": "pipeline.gather_records on %d device-resident wire records and TrainEngine.reduce_flat_gradient on the 22 MB flat buffer over the initialised process group" % n_frames}
 
 
@@ -422,6 +478,7 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
     runs = {"resident": [region(False) for _ in range(REPS)]}
     keep_res, batch_res = keep.cpu(), list(batch_of)
     link = None
+    tail_h2d = []
     if want_h2d:
         region(True)                                             # one untimed pass: first touch of the pinned pool; ITS records feed the consistency check
         keep_h2d, batch_h2d = keep.cpu(), list(batch_of)
@@ -432,6 +489,11 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
         keep_records["on"] = bool(dist_active)
         runs["h2d"] = [region(True) for _ in range(REPS)]
         keep_records["on"] = True
+        # ... so the records of the TIMED hand-over regions are checked too: what the last PIPE steps of the last timed region
+        # left in the slots' pinned host buffers must equal what the same batches gave in the resident regions
+        if not dist_active:
+            nt = min(PIPE, K)
+            tail_h2d = [(batch_of[K - nt + i], se.host_records(se._tickets - nt + i).clone()) for i in range(nt)]
         if dist_active:
             keep_h2d, batch_h2d = keep.cpu(), list(batch_of)
         # what the box's link gives: one batch, pinned host -> device, on an idle GPU (the hand-over cannot beat frames / this time)
@@ -506,6 +568,8 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
         same = consistent(keep_res, batch_res)
         if "h2d" in runs:
             same = consistent(keep_h2d, batch_h2d) and same
+            for bt, rec in tail_h2d:                             # timed hand-over regions (no bookkeeping copy): the slots' host records
+                same = same and bt in first and np.array_equal(first[bt], rec.numpy().reshape(-1)[:first[bt].size])
         wire = keep_res.numpy().view(WIRE).reshape(K, BATCH)
         recs = frames_full.numpy().view(REC).reshape(PIPE, BATCH)
         total_frames = world * K * BATCH
@@ -736,6 +800,7 @@ def main():
             out["train_step"] = train_step_leg(dev, cpu=not args.no_cpu_baseline)
             leg_s["train_step"] = round(time.perf_counter() - _t, 1)
     if rank == 0:
+        surface_in_parsed(out)
         out["leg_seconds"] = leg_s
         out["env"] = dict(env_seen, library="popnet_amd/" + os.path.basename(_pl.LIB_PATH), lab_build=bool(lab_build),
                           GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"))

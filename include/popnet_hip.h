@@ -218,6 +218,14 @@ int pn_parse_paf_unbounded(pn_ctx *ctx, const float *heat_dev, const float *paf_
 int pn_parse_paf_unbounded_fetch(pn_ctx *ctx, float *peaks_xys, int *peak_type, int *person_joint, double *person_score,
                                  int *person_count, double *joints_2d, double *joints_3d, double *part_conf);
 
+/* NMS(heatmaps, upsampFactor, bool_refine_center=True, config) (tpm/lib/utils/paf_to_pose.py:75-153) alone, on n_maps maps
+ * [n_maps, h, w] f32 of one frame (any topology: `paf_to_pose_cpp`, paf_to_pose.py:381-385, runs it on the 18 COCO parts before
+ * `process_paf`).  No capacity: count_dev [n_maps] int32 receives every map's peak count, peak_x / peak_y / peak_score_dev
+ * [n_maps][h*w] f32 the peaks of map m at [m][0 .. count[m]) in the reference's order (row-major cells): refined x, y in
+ * up-sampled pixels and the x8 bicubic score.  upsample must be 8.  Asynchronous on hip_stream.                              */
+int pn_nms_peaks(pn_ctx *ctx, const float *heat_dev, int n_maps, int h, int w, float thresh, int upsample, int *count_dev,
+                 float *peak_x_dev, float *peak_y_dev, float *peak_score_dev, void *hip_stream);
+
 /* retrieve_depth_heat_weighted(center, depthmap, heatmap, radius) (tpm/lib/utils/common.py:272-293)
  * for n centres (x, y int32 pairs) on one [h, w] f32 map pair; like the reference it first clamps
  * negative heat values in place.  out_dev: n float32 (the reference's np.sum/np.sum is float32).   */

@@ -180,6 +180,27 @@ def paf_to_pose(heatmaps, pafs):
     return joint_list, assoc
 
 
+def paf_to_pose_cpp(heatmaps, pafs, paflib, num_keypoints=18, thresh=THRESH_HEATMAP):
+    """paf_to_pose.py:381-415 (ORACLE restatement): NMS over the 18 COCO part maps -> joint_list [1, N, 5] float32 ->
+    INTER_NEAREST x8 of both maps -> process_paf + getters (`paflib`: oracle.pafprocess.restated() or .reference()) ->
+    rows [score, 18 x (x / W_up, y / H_up, part score) or -1s], the fields of the reference's Human / BodyPart objects."""
+    per_type = nms(heatmaps, num_keypoints=num_keypoints, thresh=thresh)
+    joint_list = np.array([tuple(peak) + (jt,) for jt, peaks in enumerate(per_type) for peak in peaks]).astype(np.float32)
+    rows = []
+    if joint_list.shape[0] > 0:
+        hu = cv2_resize.resize(np.ascontiguousarray(heatmaps), None, fx=DOWNSAMPLE, fy=DOWNSAMPLE, interpolation=cv2_resize.INTER_NEAREST)
+        pu = cv2_resize.resize(np.ascontiguousarray(pafs), None, fx=DOWNSAMPLE, fy=DOWNSAMPLE, interpolation=cv2_resize.INTER_NEAREST)
+        for h in paflib.run(joint_list[None], hu, pu):
+            if not h['parts']:
+                continue
+            row = -np.ones(1 + 18 * 3)
+            row[0] = h['score']
+            for p, (cid, x, y, sc) in h['parts'].items():
+                row[1 + 3 * p:4 + 3 * p] = (float(x) / hu.shape[1], float(y) / hu.shape[0], sc)
+            rows.append(row)
+    return np.array(rows, dtype=np.float64).reshape(-1, 1 + 18 * 3), per_type
+
+
 def paf_to_human_list(joint_list, person_to_joint_assoc):
     """common.py:5-32."""
     humans, visibility, conf_vec = [], [], []

@@ -124,6 +124,7 @@ _SIGNATURES = {
     "pn_slice_copy": (_i, [_vp, _vp, _i, _vp] + [_i] * 5 + [_vp]),
     "pn_sgd_nesterov": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _i, _f, _vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "pn_nms_peaks": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),
     "pn_parse_paf_unbounded": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(ParseCfg), C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
     "pn_parse_paf_unbounded_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

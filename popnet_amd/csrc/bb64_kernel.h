@@ -313,11 +313,8 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
 }
 
 static int bb64_launch(pn_ctx *ctx, const BBProblem &P, int num_cus, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bb64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS));
-        configured = true;
-    }
+    static PnLdsAttr attr;
+    if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(bb64_kernel), BB_LDS)) return rc;
     // experiment switch: POPNET_BB64_CUS = workgroups of the persistent launch (default: one per CU).  Fewer leave whole CUs to the
     // kernels of other streams while this one runs (a bb64 workgroup owns its CU's LDS).
     static int cap = -1;

@@ -377,11 +377,8 @@ __global__ __launch_bounds__(512, 1) void bb64x3_kernel(const BBProblem P) {
 }
 
 static int bb64x3_launch(pn_ctx *ctx, const BBProblem &P, int num_cus, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bb64x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS));
-        configured = true;
-    }
+    static PnLdsAttr attr;
+    if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(bb64x3_kernel), BX_LDS)) return rc;
     const int grid = P.ntiles < num_cus ? P.ntiles : num_cus;
     hipLaunchKernelGGL(bb64x3_kernel, dim3(grid), dim3(512), BX_LDS, stream, P);
     PN_HIP_CHECK(ctx, hipGetLastError());

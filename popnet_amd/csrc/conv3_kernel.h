@@ -665,12 +665,8 @@ template <int KS, int WC, int WP, int NBUF, int PT = 7, int RPG = PT * 4 / 7, in
 static int conv3_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
     auto kern = conv3_kernel<KS, WC, WP, NBUF, PT, RPG, TAIL>;
     if (L.lds_bytes > 48 * 1024) {
-        static size_t configured = 0;   // per instantiation
-        if (configured < L.lds_bytes) {
-            PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes));
-            configured = L.lds_bytes;
-        }
+        static PnLdsAttr attr;          // per instantiation, per device
+        if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(kern), L.lds_bytes)) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(L.max_blocks, L.nprob), dim3(WC * WP * 64), L.lds_bytes, stream, L.probs_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());

@@ -381,14 +381,11 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ConvProblem *__rest
 }
 
 static int conv4_launch(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream) {
-    static bool configured = false;
     // POPNET_CONV4_LDS=<bytes> (experiment): ask for more LDS than the kernel uses, e.g. 90000 = one block per CU, which leaves half of the
     // CU's registers and 70 KB of its LDS to the small launches of the other batches in flight
     static const size_t lds = getenv("POPNET_CONV4_LDS") ? std::max<size_t>(PN4_LDS, (size_t)atol(getenv("POPNET_CONV4_LDS"))) : PN4_LDS;
-    if (!configured) {
-        PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(conv4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    static PnLdsAttr attr;
+    if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(conv4_kernel), lds)) return rc;
     hipLaunchKernelGGL(conv4_kernel, dim3(L.max_blocks, L.nprob), dim3(256), lds, stream, L.probs_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;

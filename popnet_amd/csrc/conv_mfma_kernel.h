@@ -520,12 +520,8 @@ static int conv_launch_one(pn_ctx *ctx, const ConvLaunch &L, hipStream_t stream)
     if (L.lds_bytes > 160 * 1024)
         return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "conv halo tile needs %zu B of LDS", L.lds_bytes);
     if (L.lds_bytes > 48 * 1024) {
-        static size_t configured = 0;   // per instantiation
-        if (configured < L.lds_bytes) {
-            PN_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes));
-            configured = L.lds_bytes;
-        }
+        static PnLdsAttr attr;          // per instantiation, per device
+        if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(kern), L.lds_bytes)) return rc;
     }
     dim3 grid(L.max_blocks, L.nprob), block(256);
     hipLaunchKernelGGL(kern, grid, block, L.lds_bytes, stream, L.probs_dev);

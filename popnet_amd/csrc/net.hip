@@ -773,9 +773,12 @@ int build_rtpose(pn_net *n) {
     if (H % 8 || W % 8) return pn_set_error(n->ctx, PN_ERR_UNSUPPORTED, "input size must be a multiple of 8");
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     const int J1 = n->num_parts + 1, L2 = 2 * n->a, LZ = n->a + 1;      // heat / paf / z channels
-    if (L2 % 4 || J1 % 4) return pn_set_error(n->ctx, PN_ERR_UNSUPPORTED, "channel slices must be 4-aligned");
-    const int cat_c = (128 + L2 + J1 + LZ + 63) / 64 * 64;
-    const int off_paf = 128, off_heat = 128 + L2, off_z = 128 + L2 + J1;
+    // the stage-1 heads write channel slices of the concat buffer with vector stores: every slice starts on a multiple of 4 channels (the
+    // reference's default topology, 18 parts / 19 limbs = 38 + 19 + 20 channels, leaves 2 + 1 pad channels between the slices; they are
+    // never written, the buffer starts as zeros and the stage-2 weights of a pad channel are zero: rtpose_light3d.py:250,339)
+    auto up4 = [](int v) { return (v + 3) / 4 * 4; };
+    const int off_paf = 128, off_heat = up4(off_paf + L2), off_z = up4(off_heat + J1);
+    const int cat_c = (off_z + LZ + 63) / 64 * 64;
     n->out_h = H8; n->out_w = W8;
 
     int A1 = new_buf(n, H2, W2, 64), A2 = new_buf(n, H2, W2, 64), T1 = new_buf(n, H2, W2, 64);
@@ -946,6 +949,8 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
             P.Wo = (ib.W + 2 * (cs.ks / 2) - cs.ks) / cs.stride + 1;
             P.cin_chunks = cs.cin_chunks;
             P.in_cs = ib.C; P.in_coff = cs.in_coff;
+            if (n->x3 && ib.plane % 64)
+                return pn_set_error(n->ctx, PN_ERR_UNSUPPORTED, "bf16x3: input plane of %d channels is not a multiple of 64 (the K loop wraps to the hi plane per 64-channel chunk)", ib.plane);
             P.in_wrap = n->x3 ? 2 * (ib.plane / 64) : (1 << 20);      // (conv4_kernel doubles it: halves)
             P.cout = cs.cout;
             if (cs.out_buf >= 0) { P.out = n->bufs[cs.out_buf].p; P.out_cs = n->bufs[cs.out_buf].C; P.out_coff = cs.out_coff; P.split = n->x3 ? n->bufs[cs.out_buf].plane : 0; }

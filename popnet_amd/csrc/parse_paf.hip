@@ -1145,6 +1145,26 @@ extern "C" int pn_parse_paf_unbounded_fetch(pn_ctx *ctx, float *peaks_xys, int *
     return PN_OK;
 }
 
+// Stand-alone NMS (tpm/lib/utils/paf_to_pose.py:75-153 with bool_refine_center=True, no Gaussian filter) on ANY number of maps of one
+// frame: what `paf_to_pose_cpp` (paf_to_pose.py:381-385) runs before it hands the peaks to `process_paf` -- there with the 18 COCO parts, a
+// topology the three fixed-size parse kernels (15 joints / 14 limbs) do not serve.  Same kernel as the unbounded second pass: no capacity, peaks
+// of map m at [m][0 .. count[m]) in row-major cell order (= the reference's ids), refined x / y in up-sampled (x8) pixels and the bicubic score.
+extern "C" int pn_nms_peaks(pn_ctx *ctx, const float *heat_dev, int n_maps, int h, int w, float thresh, int upsample, int *count_dev,
+                            float *peak_x_dev, float *peak_y_dev, float *peak_score_dev, void *hip_stream) {
+    if (!ctx) return PN_ERR_INVALID;
+    if (ctx->device < 0) return pn_set_error(ctx, PN_ERR_STATE, "context has no device");
+    if (!heat_dev || !count_dev || !peak_x_dev || !peak_y_dev || !peak_score_dev || n_maps < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_nms_peaks: bad arguments");
+    if (h * w > MAX_MAP || h < 1 || w < 1) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_nms_peaks: map %dx%d exceeds %d cells", h, w, MAX_MAP);
+    if (upsample != 8) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_nms_peaks: built for upsampFactor = 8 (MODEL.DOWNSAMPLE)");
+    CubicTab tab;
+    for (int p = 0; p < 8; ++p) host_cubic_coeffs((float)(2 * p + 1) / 16.0f, tab.c[p]);
+    BigWs W = {};
+    W.peak_count = count_dev; W.px = peak_x_dev; W.py = peak_y_dev; W.ps = peak_score_dev;
+    hipLaunchKernelGGL(big_peaks_kernel, dim3(n_maps), dim3(256), 0, (hipStream_t)hip_stream, heat_dev, h, w, thresh, tab, W);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
 void pn_parse_big_free(pn_ctx *ctx) {
     BigHost *B = (BigHost *)ctx->parse_big;
     if (!B) return;

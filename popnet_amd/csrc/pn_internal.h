@@ -30,6 +30,7 @@ struct pn_ctx {
     std::vector<PackEntry> train_packs;
     void *train_pack_table = nullptr;      // device copy of the descriptor table
     size_t train_pack_table_entries = 0;   // entries the device table holds (re-uploaded when the host list has grown)
+    size_t train_pack_table_cap = 0;       // entries the block has room for: append-only inside it (a captured graph keeps pointing at it)
     unsigned train_pack_blocks = 0;
 };
 
@@ -43,6 +44,17 @@ void pn_parse_big_free(pn_ctx *ctx);     // parse_paf.hip
             return pn_set_error((ctx), PN_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
                                 hipGetErrorString(_e), __FILE__, __LINE__);                  \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: every launch site keeps one of these (a static
+// per kernel instantiation) and opts in once per device it launches on (a process-wide flag left a second GPU unconfigured).
+struct PnLdsAttr { size_t bytes[64] = {}; };
+inline int pn_lds_attr(pn_ctx *ctx, PnLdsAttr &st, const void *kern, size_t bytes) {
+    const int d = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if (st.bytes[d] >= bytes) return PN_OK;
+    PN_HIP_CHECK(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    st.bytes[d] = bytes;
+    return PN_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Convolution problem descriptor (device-visible).  One launch handles a GROUP of problems that

@@ -1633,6 +1633,7 @@ int pn_train_pack_cache(pn_ctx *ctx, int enable) {
         if (ctx->train_pack_table) (void)hipFree(ctx->train_pack_table);
         ctx->train_pack_table = nullptr;
         ctx->train_pack_table_entries = 0;
+        ctx->train_pack_table_cap = 0;
     }
     ctx->train_pack_cache = enable != 0;
     return PN_OK;
@@ -1658,8 +1659,22 @@ int pn_train_pack_refresh(pn_ctx *ctx, void *hip_stream) {
             blocks += (unsigned)((items + 255) / 256);
         }
         PN_HIP_CHECK(ctx, hipStreamSynchronize(s));
-        if (ctx->train_pack_table) (void)hipFree(ctx->train_pack_table);
-        PN_HIP_CHECK(ctx, hipMalloc(&ctx->train_pack_table, n * sizeof(TPackDesc)));
+        // The table is APPEND-ONLY in a fixed-capacity block: a captured step graph bakes (table pointer, entry count, grid) into its
+        // wpack_all_kernel node, and an eager step of another resolution after capture() adds (w, Cout, Cin, flip, x3) keys.  Entries
+        // 0 .. n_old - 1 keep their bytes and their block offsets, so the replayed node stays valid (the table used to be
+        // freed and reallocated here -- a replay then read freed memory).  Beyond the capacity the old block is retired, not freed,
+        // while a graph may point at it (pn_train_ws_keep), exactly like train_ws.
+        if (n > ctx->train_pack_table_cap) {
+            size_t cap = std::max<size_t>(256, ctx->train_pack_table_cap * 2);
+            while (cap < n) cap *= 2;
+            if (ctx->train_pack_table) {
+                if (ctx->train_ws_keep) ctx->train_ws_retired.push_back(ctx->train_pack_table);
+                else (void)hipFree(ctx->train_pack_table);
+                ctx->train_pack_table = nullptr;
+            }
+            PN_HIP_CHECK(ctx, hipMalloc(&ctx->train_pack_table, cap * sizeof(TPackDesc)));
+            ctx->train_pack_table_cap = cap;
+        }
         PN_HIP_CHECK(ctx, hipMemcpy(ctx->train_pack_table, host.data(), n * sizeof(TPackDesc), hipMemcpyHostToDevice));
         ctx->train_pack_table_entries = n;
         ctx->train_pack_blocks = blocks;

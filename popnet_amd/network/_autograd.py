@@ -140,7 +140,20 @@ def bn_act(x, m, act, res=None):
     if m.num_batches_tracked is not None:
         m.num_batches_tracked.add_(1)
     if m.momentum is None:          # torch: cumulative moving average, factor 1 / num_batches_tracked (nn.modules.batchnorm._BatchNorm.forward)
-        momentum = 1.0 / float(m.num_batches_tracked) if m.num_batches_tracked is not None else 0.0
+        # The counter lives on the device: reading it every call is a host sync per BatchNorm layer (and illegal under stream capture).
+        # A host-side twin, seeded once from the buffer and re-seeded whenever the buffer object or its version moved behind our back
+        # (load_state_dict, .to()), counts the calls instead.
+        nb = m.num_batches_tracked
+        if nb is None:
+            momentum = 0.0
+        else:
+            twin = m.__dict__.get("_popnet_nbt")
+            if twin is None or twin[0] != nb.data_ptr() or twin[1] != nb._version - 1:
+                count = int(nb)                      # one sync: first call, or somebody else wrote the buffer
+            else:
+                count = twin[2] + 1
+            m.__dict__["_popnet_nbt"] = (nb.data_ptr(), nb._version, count)
+            momentum = 1.0 / float(count)
     else:
         momentum = m.momentum
     return BatchNormActFn.apply(x, m.weight, m.bias, res, m.running_mean, m.running_var, act, momentum, m.eps)

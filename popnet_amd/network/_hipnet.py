@@ -45,17 +45,32 @@ class HipNetModule(nn.Module):
         looked up afresh every time.
         Writers that go through raw device pointers (the HIP training primitives updating BatchNorm running statistics, a TrainEngine
         writing into module buffers) do NOT bump `_version`: they must call invalidate() -- `_forward_train` does."""
-        slots = self.__dict__.get("_version_tensors")
-        if slots is None:                      # (owner dict, name) of every parameter / buffer slot: a RE-ASSIGNED tensor is still seen
-            slots = []
+        cache = self.__dict__.get("_version_tensors")
+        if cache is not None:
+            # structural check (ADVICE r04): a replaced sub-module (model.model0.conv1 = nn.Conv2d(...)), a slot registered later
+            # (register_buffer / register_parameter / add_module) or a slot count that changed makes the cached slot list stale
+            for d, n in cache[1]:
+                if len(d) != n:
+                    cache = None
+                    break
+            else:
+                for d, k, ident in cache[2]:
+                    if id(d.get(k)) != ident:
+                        cache = None
+                        break
+        if cache is None:                      # (owner dict, name) of every parameter / buffer slot: a RE-ASSIGNED tensor is still seen
+            slots, sizes, kids = [], [], []
             for mod in self.modules():
-                slots += [(mod._parameters, k) for k, v in mod._parameters.items() if v is not None]
-                slots += [(mod._buffers, k) for k, v in mod._buffers.items() if v is not None]
-            self.__dict__["_version_tensors"] = slots
+                slots += [(mod._parameters, k) for k in mod._parameters]
+                slots += [(mod._buffers, k) for k in mod._buffers]
+                sizes += [(mod._parameters, len(mod._parameters)), (mod._buffers, len(mod._buffers)), (mod._modules, len(mod._modules))]
+                kids += [(mod._modules, k, id(c)) for k, c in mod._modules.items()]
+            cache = (slots, sizes, kids)
+            self.__dict__["_version_tensors"] = cache
         out = []
-        for d, k in slots:
-            t = d[k]
-            out.append((t.data_ptr(), t._version))
+        for d, k in cache[0]:
+            t = d.get(k)
+            out.append((0, 0) if t is None else (t.data_ptr(), t._version))      # a slot that is (or became) None is a value like any other
         return tuple(out)
 
     def _apply(self, fn, *a, **kw):

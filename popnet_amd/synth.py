@@ -126,6 +126,50 @@ def planted_maps(seed, n_persons, h=28, w=28, stride=8, sigma=0.8, noise=0.01, d
             np.clip(z, -2, 2).astype(np.float32))
 
 
+# COCO-18 topology of the `pafprocess` plug-in (tpm/lib/pafprocess/pafprocess.h:8-13): limb l joins parts COCO_PAIRS[l], its PAF x / y
+# channels are COCO_PAIRS_NET[l]
+COCO_PAIRS = [(1, 2), (1, 5), (2, 3), (3, 4), (5, 6), (6, 7), (1, 8), (8, 9), (9, 10), (1, 11), (11, 12), (12, 13), (1, 0),
+              (0, 14), (14, 16), (0, 15), (15, 17), (2, 16), (5, 17)]
+COCO_PAIRS_NET = [(12, 13), (20, 21), (14, 15), (16, 17), (22, 23), (24, 25), (0, 1), (2, 3), (4, 5), (6, 7), (8, 9), (10, 11),
+                  (28, 29), (30, 31), (34, 35), (32, 33), (36, 37), (18, 19), (26, 27)]
+_COCO_TMPL = np.array([[.5, .08], [.5, .2], [.38, .22], [.33, .38], [.3, .52], [.62, .22], [.67, .38], [.7, .52], [.44, .55],
+                       [.43, .75], [.42, .95], [.56, .55], [.57, .75], [.58, .95], [.47, .05], [.53, .05], [.43, .07], [.57, .07]])
+
+
+def coco_maps(seed, n_persons, h=28, w=28, sigma=0.9, noise=0.01, drop_prob=0.08):
+    """Network-resolution maps of the COCO-18 caller of the path (`paf_to_pose_cpp`, tpm/lib/utils/paf_to_pose.py:381-415): heat [h, w, 19]
+    with a Gaussian bump per visible part (plus the background channel), paf [h, w, 38] with unit vectors along every limb whose two parts
+    are present, small noise everywhere.  Seeded: golden generator and tests build the same arrays."""
+    rng = np.random.default_rng(seed)
+    heat = rng.normal(0, noise, (h, w, 19)).astype(np.float32)
+    paf = rng.normal(0, noise, (h, w, 38)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    for _ in range(n_persons):
+        hgt = rng.uniform(0.55, 0.9) * h
+        wid = hgt * 0.6
+        x0, y0 = rng.uniform(0.5, max(0.6, w - wid - 0.5)), rng.uniform(0.5, max(0.6, h - hgt - 0.5))
+        pts = _COCO_TMPL * [wid, hgt] + [x0, y0]
+        keep = rng.random(18) >= drop_prob
+        amp = rng.uniform(0.5, 0.95, 18)
+        for j in range(18):
+            if keep[j]:
+                heat[:, :, j] = np.maximum(heat[:, :, j], (amp[j] * np.exp(-((xx - pts[j, 0]) ** 2 + (yy - pts[j, 1]) ** 2) / (2 * sigma ** 2))).astype(np.float32))
+        for l, (a, b) in enumerate(COCO_PAIRS):
+            if not (keep[a] and keep[b]):
+                continue
+            d = pts[b] - pts[a]
+            n = float(np.hypot(*d))
+            if n < 1e-6:
+                continue
+            u = d / n
+            rx, ry = xx - pts[a, 0], yy - pts[a, 1]
+            along, across = rx * u[0] + ry * u[1], np.abs(rx * u[1] - ry * u[0])
+            m = (along >= -0.5) & (along <= n + 0.5) & (across <= 0.8)
+            paf[:, :, COCO_PAIRS_NET[l][0]][m] = np.float32(u[0])
+            paf[:, :, COCO_PAIRS_NET[l][1]][m] = np.float32(u[1])
+    return heat, paf
+
+
 def planted_batch(seed, persons_per_frame, **kw):
     """Stacks planted_maps into NCHW float32 arrays: heat [B,16,h,w], paf [B,28,h,w], z [B,15,h,w]."""
     hs, ps, zs = [], [], []

@@ -13,7 +13,9 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import pafprocess
 from ..config import LIMBS
+from .common_coco import BodyPart, Human
 
 # same module-level names as the reference (paf_to_pose.py:28-30)
 joint_to_limb_heatmap_relationship = [list(l) for l in LIMBS]
@@ -132,3 +134,69 @@ def paf_to_pose(heatmaps, pafs, config):
         r = parse_paf_unbounded(hm[0], pf[0], z[0], cfg)
         return r["joint_list"], r["person_to_joint_assoc"]
     return frame_joint_list(fr), frame_assoc(fr)
+
+
+def NMS(heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=False, config=None):
+    """tpm/lib/utils/paf_to_pose.py:75-153 on the GPU (pn_nms_peaks): heatmaps [h, w, >= NUM_KEYPOINTS] float32 (ndarray or CUDA tensor)
+    -> a list of NUM_KEYPOINTS float64 arrays [n_j, 4] (x, y, score, running id), any number of maps (the COCO-18 caller included).
+    Only the reference's default path is built: refined centres, no Gaussian filter, upsampFactor = 8."""
+    if not bool_refine_center or bool_gaussian_filt:
+        raise _lib.PopnetError("NMS: only bool_refine_center=True, bool_gaussian_filt=False is built (the reference's defaults)")
+    if int(upsampFactor) != upsampFactor or int(upsampFactor) != 8:
+        raise _lib.PopnetError("NMS: built for upsampFactor = 8 (MODEL.DOWNSAMPLE)")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hm = torch.as_tensor(np.ascontiguousarray(heatmaps) if isinstance(heatmaps, np.ndarray) else heatmaps)
+    nk = int(config.MODEL.NUM_KEYPOINTS)
+    hm = hm.to(dev, torch.float32).permute(2, 0, 1)[:nk].contiguous()
+    _, h, w = hm.shape
+    cnt = torch.zeros((nk,), device=dev, dtype=torch.int32)
+    xs, ys, sc = (torch.empty((nk, h * w), device=dev, dtype=torch.float32) for _ in range(3))
+    ctx = _lib.Context.for_device(dev.index)
+    ctx.check(_lib.lib().pn_nms_peaks(ctx.handle, C.c_void_p(hm.data_ptr()), nk, h, w, float(config.TEST.THRESH_HEATMAP), 8,
+                                      C.c_void_p(cnt.data_ptr()), C.c_void_p(xs.data_ptr()), C.c_void_p(ys.data_ptr()),
+                                      C.c_void_p(sc.data_ptr()), _lib.current_stream_ptr(dev)), "pn_nms_peaks")
+    cnt = cnt.cpu().numpy()
+    xs, ys, sc = xs.cpu().numpy(), ys.cpu().numpy(), sc.cpu().numpy()
+    out, total = [], 0
+    for j in range(nk):
+        n = int(cnt[j])
+        peaks = np.zeros((n, 4))
+        peaks[:, 0], peaks[:, 1], peaks[:, 2] = xs[j, :n], ys[j, :n], sc[j, :n]
+        peaks[:, 3] = np.arange(total, total + n)
+        total += n
+        out.append(peaks)
+    return out
+
+
+def paf_to_pose_cpp(heatmaps, pafs, config):
+    """tpm/lib/utils/paf_to_pose.py:381-415: NMS -> joint_list [1, N, 5] float32 -> INTER_NEAREST x DOWNSAMPLE up-sampling of both maps ->
+    `process_paf` + the six getters -> a list of `Human`s.  heatmaps [h, w, 19], pafs [h, w, 38] float32 HWC (COCO-18 topology, hard-coded
+    on the C++ side: pafprocess.h:8-13).  NMS and process_paf run in libpopnet_hip.so; the nearest-neighbour up-sampling is an index
+    repeat (cv2.INTER_NEAREST at an integer factor reads source cell floor(d / f))."""
+    humans = []
+    joint_list_per_joint_type = NMS(heatmaps, upsampFactor=config.MODEL.DOWNSAMPLE, config=config)
+    joint_list = np.array([tuple(peak) + (joint_type,) for joint_type, joint_peaks in enumerate(joint_list_per_joint_type)
+                           for peak in joint_peaks]).astype(np.float32)
+    if joint_list.shape[0] > 0:
+        joint_list = np.expand_dims(joint_list, 0)
+        f = int(config.MODEL.DOWNSAMPLE)
+        to_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        paf_upsamp = np.repeat(np.repeat(to_np(pafs), f, axis=0), f, axis=1)
+        heatmap_upsamp = np.repeat(np.repeat(to_np(heatmaps), f, axis=0), f, axis=1)
+        pafprocess.process_paf(joint_list, heatmap_upsamp, paf_upsamp)
+        for human_id in range(pafprocess.get_num_humans()):
+            human = Human([])
+            is_added = False
+            for part_idx in range(config.MODEL.NUM_KEYPOINTS):
+                c_idx = int(pafprocess.get_part_cid(human_id, part_idx))
+                if c_idx < 0:
+                    continue
+                is_added = True
+                human.body_parts[part_idx] = BodyPart('%d-%d' % (human_id, part_idx), part_idx,
+                                                      float(pafprocess.get_part_x(c_idx)) / heatmap_upsamp.shape[1],
+                                                      float(pafprocess.get_part_y(c_idx)) / heatmap_upsamp.shape[0],
+                                                      pafprocess.get_part_score(c_idx))
+            if is_added:
+                human.score = pafprocess.get_score(human_id)
+                humans.append(human)
+    return humans

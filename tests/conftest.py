@@ -22,6 +22,7 @@ def golden():
         parse = np.load(os.path.join(GOLDEN, "parse_paf.npz"))
         yolo = np.load(os.path.join(GOLDEN, "parse_yolo.npz"))
         pafprocess = np.load(os.path.join(GOLDEN, "pafprocess.npz"))
+        cpp = np.load(os.path.join(GOLDEN, "paf_to_pose_cpp.npz"))
         keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
         script = json.load(open(os.path.join(GOLDEN, "script_eval_data.json")))
         script_yolo = json.load(open(os.path.join(GOLDEN, "script_eval_data_yolo.json")))

@@ -345,6 +345,57 @@ def golden_pafprocess():
     np.savez_compressed(os.path.join(OUT, "pafprocess.npz"), **out)
 
 
+# ---- F4b: paf_to_pose_cpp, the reference's Python caller of process_paf -------------------------
+CPP_CASES = ((60, 1), (61, 2), (62, 3), (63, 0), (64, 5))
+
+
+def humans_objects_to_array(humans):
+    """[n, 1 + 18*3]: human.score, then per COCO part (x, y, score) of human.body_parts or -1s -- everything coco_eval.py:270-290 reads."""
+    arr = -np.ones((len(humans), 1 + 18 * 3), dtype=np.float64)
+    for i, h in enumerate(humans):
+        arr[i, 0] = h.score
+        for p, bp in h.body_parts.items():
+            assert bp.part_idx == p and bp.uidx.endswith("-%d" % p)
+            arr[i, 1 + 3 * p:4 + 3 * p] = (bp.x, bp.y, bp.score)
+    return arr
+
+
+def golden_paf_to_pose_cpp():
+    """The reference function tpm/lib/utils/paf_to_pose.py:381-415 itself, on seeded COCO-18 maps, with the reference's own pafprocess.cpp
+    (compiled as-is into oracle/_ref) behind the module name the function expects -- the reference ships that import commented out
+    (paf_to_pose.py:7), so the name is bound here the way coco_eval.py's environment would bind it."""
+    import types
+    import ctypes as C
+    from types import SimpleNamespace
+    from oracle import pafprocess as pp
+    from popnet_amd import synth
+    import lib.utils.paf_to_pose as ref_mod
+    pp.build()
+    ref = pp.reference()
+    assert ref is not None, "oracle/_ref/libpafprocess_ref.so missing (make -C oracle)"
+    shim = types.ModuleType("pafprocess")
+
+    def process_paf(peaks, heat, paf):
+        peaks, heat, paf = (np.ascontiguousarray(a, dtype=np.float32) for a in (peaks, heat, paf))
+        fp = C.POINTER(C.c_float)
+        return ref._pp(*peaks.shape, peaks.ctypes.data_as(fp), *heat.shape, heat.ctypes.data_as(fp), *paf.shape, paf.ctypes.data_as(fp))
+    shim.process_paf = process_paf
+    for k in ("get_num_humans", "get_part_cid", "get_score", "get_part_x", "get_part_y", "get_part_score"):
+        setattr(shim, k, ref._g[k])
+    ref_mod.pafprocess = shim
+    cfg = SimpleNamespace(MODEL=SimpleNamespace(DOWNSAMPLE=8, NUM_KEYPOINTS=18), TEST=SimpleNamespace(THRESH_HEATMAP=0.1))
+    out = {}
+    for seed, P in CPP_CASES:
+        heat, paf = synth.coco_maps(seed, P)
+        humans = ref_mod.paf_to_pose_cpp(heat.copy(), paf.copy(), cfg)
+        out["s%d_p%d" % (seed, P)] = humans_objects_to_array(humans)
+        nms = ref_mod.NMS(heat.copy(), upsampFactor=8, config=cfg)
+        out["s%d_p%d_nms" % (seed, P)] = np.array([tuple(pk) + (j,) for j, pks in enumerate(nms) for pk in pks], dtype=np.float64).reshape(-1, 5)
+        out["s%d_p%d_insum" % (seed, P)] = np.array([float(heat.astype(np.float64).sum()), float(paf.astype(np.float64).sum())])
+        print("F4b paf_to_pose_cpp seed %d P=%d -> %d peaks, %d humans" % (seed, P, len(out["s%d_p%d_nms" % (seed, P)]), len(humans)))
+    np.savez_compressed(os.path.join(OUT, "paf_to_pose_cpp.npz"), **out)
+
+
 # ---- F6: the reference evaluation SCRIPT, end to end, on a fake two-frame dataset ---------------
 def calibrated_heat_bias(model, x, frac=0.004):
     """Per-channel stage-2 heat bias shift so ~frac of the cells pass THRESH_HEATMAP (CPU twin of
@@ -865,9 +916,9 @@ if __name__ == "__main__":
     args = [a for a in args if a != "--check"]
     if check:
         OUT = tempfile.mkdtemp(prefix="popnet_golden_check_")
-    which = args or ["keys", "forward", "parse", "yolo", "pafprocess", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo", "targets", "train"]
+    which = args or ["keys", "forward", "parse", "yolo", "pafprocess", "cpp", "script", "script_yolo", "metrics", "script_metrics", "script_metrics_yolo", "targets", "train"]
     fns = {"keys": golden_state_dicts, "forward": golden_forward, "parse": golden_parse, "yolo": golden_yolo,
-           "pafprocess": golden_pafprocess, "script": golden_script,
+           "pafprocess": golden_pafprocess, "cpp": golden_paf_to_pose_cpp, "script": golden_script,
            "script_yolo": golden_script_yolo, "metrics": golden_metrics, "script_metrics": golden_script_metrics,
            "script_metrics_yolo": lambda: golden_script_metrics("yolo"), "targets": golden_targets, "train": golden_train}
     for w in which:

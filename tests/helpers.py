@@ -115,6 +115,7 @@ def humans_to_array(humans):
 
 
 PAFPROCESS_CASES = [(40, 1), (41, 2), (42, 4), (43, 0), (44, 6)]
+CPP_CASES = [(60, 1), (61, 2), (62, 3), (63, 0), (64, 5)]      # tests/golden/make_golden.py::CPP_CASES (paf_to_pose_cpp on synth.coco_maps)
 
 
 # ---- training goldens (must mirror tests/golden/make_golden.py::train_case_inputs / sample_indices) ----

@@ -18,4 +18,4 @@ def test_default_all_steps_run_regenerates_every_golden_file_identically():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden.py"), "--check"],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "golden check ok: 12 files regenerate identically" in r.stdout
+    assert "golden check ok: 13 files regenerate identically" in r.stdout

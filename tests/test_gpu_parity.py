@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (PAFPROCESS_CASES, YOLO_ANCHORS, all_parse_case_names, coco_case, humans_to_array,
+from helpers import (CPP_CASES, PAFPROCESS_CASES, YOLO_ANCHORS, all_parse_case_names, coco_case, humans_to_array,
                      parse_case_inputs, state_dict_from_keys, yolo_maps)
 from popnet_amd import _lib, synth
 from popnet_amd.config import default_cfg
@@ -173,6 +173,45 @@ def test_multi_channel_input_vs_oracle(gpu, golden, prec, tol):
     d = (out.cpu() - ref).abs()
     # the single-channel Yolo tests' tolerances (activations reach |x| ~ 150 with these weights); plain bf16 flips saturated sigmoid casts
     # outright (range [-2, 2]): bounded in the mean, as the bf16 rtpose maps are
+    assert torch.isfinite(out).all()
+    if prec == "bf16":
+        assert float(d.mean()) < 0.05, float(d.mean())
+    else:
+        assert float(d.max()) < {"fp32": 2e-3, "bf16x3": 5e-3}[prec], float(d.max())
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16x3", 5e-4), ("bf16", 0.15)])
+def test_default_constructor_topology_vs_oracle(gpu, prec, tol):
+    """`rtpose_light3d()` exactly as the reference constructs it by default (rtpose_light3d.py:250: 18 parts, 19 limbs, 2 stages, 3 input
+    channels): 38 + 19 + 20 head channels, a 205-channel stage-2 input (rtpose_light3d.py:283-304,339) whose slices are NOT multiples of 4
+    channels wide -- the concat buffer pads them (net.hip::build_rtpose).  Stage-2 maps and the stage-1 maps inside the concat buffer
+    against the oracle's torch fp32 forward of the same state_dict, every precision mode; `YoloPoseNet()` (15 parts, 3 channels) likewise."""
+    from oracle import nets
+    from popnet_amd.network.rtpose_light3d import rtpose_light3d
+    from popnet_amd.network.yolo_posenet import YoloPoseNet
+    x = torch.from_numpy(np.random.default_rng(57).normal(0, 1, (3, 3, 224, 224)).astype(np.float32))
+    m = rtpose_light3d().eval()
+    assert (m.num_parts, m.num_limbs, m.num_stages, m.input_dim) == (18, 19, 2, 3)
+    assert tuple(m.state_dict()["model2_1.0.weight"].shape) == (256, 205, 3, 3)
+    synth.load_synth_weights(m, seed=8)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.precision = prec
+    (p, h, z), saved = m(x.to(gpu))
+    torch.cuda.synchronize()
+    assert tuple(p.shape) == (3, 38, 28, 28) and tuple(h.shape) == (3, 19, 28, 28) and tuple(z.shape) == (3, 20, 28, 28)
+    (rp, rh, rz), inter = nets.rtpose_light3d_forward(x, sd, return_intermediate=True)
+    for got, ref, name in ((p, rp, "paf"), (h, rh, "heat"), (z, rz, "z"), (saved[0], inter["paf1"], "paf1"), (saved[1], inter["heat1"], "heat1"),
+                           (saved[2], inter["z1"], "z1")):
+        d = (got.cpu() - ref).abs()
+        assert torch.isfinite(got).all() and float(d.max()) < tol, (name, float(d.max()))
+    my = YoloPoseNet().eval()
+    assert (my.num_parts, my.input_dim) == (15, 3)
+    synth.load_synth_weights(my, seed=9)
+    sdy = {k: v.detach().clone() for k, v in my.state_dict().items()}
+    my.precision = prec
+    out = my(x.to(gpu))
+    torch.cuda.synchronize()
+    d = (out.cpu() - nets.yolo_posenet_forward(x, sdy)).abs()
     assert torch.isfinite(out).all()
     if prec == "bf16":
         assert float(d.mean()) < 0.05, float(d.mean())
@@ -669,6 +708,31 @@ def test_pafprocess_abi_vs_compiled_reference_golden(gpu, golden, seed, P):
     pk, heat, paf = coco_case(seed, P)
     got = humans_to_array(pafprocess.run(pk, heat, paf))
     assert np.array_equal(got, golden.pafprocess["s%d_p%d" % (seed, P)])
+
+
+@pytest.mark.parametrize("seed,P", CPP_CASES)
+def test_paf_to_pose_cpp_vs_reference_function_golden(gpu, golden, seed, P):
+    """popnet_amd.utils.paf_to_pose.paf_to_pose_cpp (NMS on the GPU -> INTER_NEAREST x8 -> process_paf + getters in libpopnet_hip.so) ==
+    the reference's own function (tpm/lib/utils/paf_to_pose.py:381-415) with its compiled pafprocess.cpp behind it: the NMS rows and
+    every field of every Human / BodyPart, bit for bit."""
+    from types import SimpleNamespace
+    from popnet_amd import synth
+    from popnet_amd.utils import paf_to_pose as P2P
+    cfg = SimpleNamespace(MODEL=SimpleNamespace(DOWNSAMPLE=8, NUM_KEYPOINTS=18), TEST=SimpleNamespace(THRESH_HEATMAP=0.1))
+    heat, paf = synth.coco_maps(seed, P)
+    g = golden.cpp
+    nms = P2P.NMS(heat.copy(), upsampFactor=8, config=cfg)
+    rows = np.array([tuple(pk) + (j,) for j, pks in enumerate(nms) for pk in pks], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(rows, g["s%d_p%d_nms" % (seed, P)])
+    humans = P2P.paf_to_pose_cpp(heat.copy(), paf.copy(), cfg)
+    got = -np.ones((len(humans), 1 + 18 * 3))
+    for i, h in enumerate(humans):
+        got[i, 0] = h.score
+        for p, bp in h.body_parts.items():
+            assert bp.part_idx == p and bp.uidx.endswith("-%d" % p)
+            got[i, 1 + 3 * p:4 + 3 * p] = (bp.x, bp.y, bp.score)
+    assert np.array_equal(got, g["s%d_p%d" % (seed, P)])
+    assert (len(humans) > 0) == (P > 0)
 
 
 def test_pafprocess_rejects_out_of_range_peaks(gpu):

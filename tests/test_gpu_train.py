@@ -540,6 +540,29 @@ def test_captured_training_step_equals_eager(gpu, golden):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_captured_step_survives_eager_steps_of_other_shapes(gpu, golden, prec):
+    """a captured step graph bakes the weight-pack descriptor table (pointer, entry count, grid) into its wpack_all_kernel
+    node; eager steps at OTHER resolutions after capture() add pack keys (another tile geometry = another (flip, x3) form of the same
+    weights) and used to free and reallocate that table.  Now the table is append-only in a fixed block: the replay right after such
+    steps still equals an eager engine bit for bit, in both precisions."""
+    from popnet_amd.train import TrainEngine
+    sd = init_like_state_dict(golden.keys["rtpose_light3d"], seed=5)
+    mk = lambda seed, B, H, W: [torch.from_numpy(a).to(gpu) for a in train_case_inputs(seed=seed, B=B, H=H, W=W)]
+    b0, b1 = mk(800, 2, 64, 96), mk(801, 2, 64, 96)
+    eager, graph = TrainEngine(sd, device=gpu, lr=0.05, precision=prec), TrainEngine(sd, device=gpu, lr=0.05, precision=prec)
+    graph.capture(*b0)
+    for _ in range(2):
+        eager.step(*b0)
+    for shape in ((1, 224, 224), (3, 96, 128), (1, 40, 56), (2, 128, 64)):
+        other = mk(900 + shape[1], *shape)
+        assert torch.equal(eager.step(*other).clone(), graph.step(*other).clone()), shape
+        for b in (b0, b1):                           # replays of the captured shape in between
+            assert torch.equal(eager.step(*b).clone(), graph.step(*b).clone()), shape
+    torch.cuda.synchronize()
+    assert torch.equal(eager.flat_p, graph.flat_p) and torch.equal(eager.flat_m, graph.flat_m)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 def test_weight_pack_cache_equals_per_call_packs(gpu, golden, prec):
     """Round 4: the packed weights of the 3x3 training convolutions are cached in the engine's context and refreshed by
     ONE launch per step (pn_train_pack_refresh) instead of one pack launch per convolution call.  Same pack arithmetic: an engine with the

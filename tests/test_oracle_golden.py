@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (PAFPROCESS_CASES, YOLO_ANCHORS, all_parse_case_names, coco_case, humans_to_array,
+from helpers import (CPP_CASES, PAFPROCESS_CASES, YOLO_ANCHORS, all_parse_case_names, coco_case, humans_to_array,
                      parse_case_inputs, state_dict_from_keys, yolo_maps, yolo_maps_predvis)
 from oracle import cv2_resize, nets, parse_paf, parse_yolo, preproc
 from popnet_amd import synth
@@ -85,6 +85,20 @@ def test_pafprocess_restatement_matches_compiled_reference(golden, seed, P):
     ref = pp.reference()          # the reference's own C++ (oracle/_ref), when it has been built
     if ref is not None:
         assert np.array_equal(humans_to_array(ref.run(pk, heat, paf)), want)
+
+
+@pytest.mark.parametrize("seed,P", CPP_CASES)
+def test_paf_to_pose_cpp_restatement_matches_reference_function(golden, seed, P):
+    """oracle.parse_paf.paf_to_pose_cpp == the reference's paf_to_pose_cpp (paf_to_pose.py:381-415) run on the reference's own compiled
+    pafprocess.cpp (tests/golden/make_golden.py::golden_paf_to_pose_cpp): NMS rows and every Human / BodyPart field."""
+    from oracle import pafprocess as pp
+    heat, paf = synth.coco_maps(seed, P)
+    g = golden.cpp
+    assert np.array_equal(g["s%d_p%d_insum" % (seed, P)], [float(heat.astype(np.float64).sum()), float(paf.astype(np.float64).sum())])
+    rows, per_type = parse_paf.paf_to_pose_cpp(heat.copy(), paf.copy(), pp.restated())
+    nms = np.array([tuple(pk) + (j,) for j, pks in enumerate(per_type) for pk in pks], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(nms, g["s%d_p%d_nms" % (seed, P)])
+    assert np.array_equal(rows, g["s%d_p%d" % (seed, P)])
 
 
 def test_script_level_pipeline_matches_reference_eval_script(golden):
