@@ -34,12 +34,34 @@ struct TConv {
 #define TC_AP 80      // LDS pitches: 4 k rows x 16 lanes of an MFMA operand read fall on 64 different banks
 #define TC_BP 144
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Reuse-aware block order (round 5).  The dispatcher deals the workgroups of a launch round-robin over the 8 XCDs in linear-id order
+// (x fastest) and every XCD has its own 4 MB L2.  With the plain (tile, cout block) / (ci block, cout block, slice) grids the blocks
+// that read the SAME operand tile -- the cout blocks of one input tile in the forward / data-gradient kernels, the (ci, cout) blocks of
+// one pixel slice in the weight gradient -- sat on different XCDs or ran a whole grid apart in time: every operand tile crossed the
+// fabric once per sharer (a 256 -> 256 weight gradient staged 444 MB for 51 MB of tensors).  t_logical_block() maps the hardware id to
+// a LOGICAL id such that each XCD owns one contiguous range of logical ids (a bijection, the conv kernels' remap of net.hip); the
+// kernels decode the logical id with the sharing dimension fastest, so sharers run at the same time behind the same L2.  Which block
+// computes which tile changes, nothing else: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int t_logical_block() {
+    const int nb = (int)(gridDim.x * gridDim.y * gridDim.z);
+    const int L = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    const int xcd = L & 7, idx = L >> 3, qq = nb >> 3, rr = nb & 7;
+    return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+}
+// forward-type grids (tiles, cout blocks): the cout blocks of a tile are neighbours in logical order
+#define T_DECODE_TILE_CB(tile, cb) const int _lg = t_logical_block(), cb = _lg % (int)gridDim.y, tile = _lg / (int)gridDim.y
+// weight-gradient grids (column blocks, cout blocks, slices): a slice's blocks are one contiguous logical range
+#define T_DECODE_XYZ(bx, by, bz) const int _lg = t_logical_block(), bx = _lg % (int)gridDim.x, by = (_lg / (int)gridDim.x) % (int)gridDim.y, bz = _lg / (int)(gridDim.x * gridDim.y)
+
 template <int KS>
 __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
     __shared__ float As[TC_KC][TC_AP];
     __shared__ float Bs[TC_KC][TC_BP];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int p0 = blockIdx.x * 128, co0 = blockIdx.y * 64;
+    T_DECODE_TILE_CB(pblk, cblk);
+    const int p0 = pblk * 128, co0 = cblk * 64;
     const int HoWo = c.Ho * c.Wo;
     // staging roles
     const int b_pn = t & 127, b_k0 = t >> 7;            // B: pixel column, k rows b_k0 + 2j
@@ -172,8 +194,9 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
     float *As = t_smem;                       // [9 * 16][TT_AP]   weights  (tap, channel) x cout
     float *Hs = t_smem + 144 * TT_AP;         // [16][CHP]         halo tile of 16 input channels
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int b = blockIdx.x, tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
-    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = blockIdx.y * 64;
+    T_DECODE_TILE_CB(b, cblk);
+    const int tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
+    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = cblk * 64;
     const int HW = c.H * c.W, HoWo = c.Ho * c.Wo;
     // this lane's two pixel slots (MFMA columns)
     int hb[2], opix[2];
@@ -311,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void tconv3_wgrad_tile_kernel(TConv c, TTil
     float *Hs = t_smem + 128 * TT_YP;           // [HR * HC][TT_HP]  halo tile of this block's 16 input channels, pixel-major
     int *hbt = (int *)(Hs + g.HR * g.HC * TT_HP);   // [128]       pixel slot -> halo pixel of its top-left tap
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int c0 = blockIdx.x * 16, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    T_DECODE_XYZ(bx_, by_, slice);
+    const int c0 = bx_ * 16, co0 = by_ * 64;
     const int HW = c.H * c.W, HoWo = c.Ho * c.Wo;
     // per-thread constants of the staging: the dY slot and the halo elements (same for every tile up to the tile origin)
     const int sl = t & 127, ry = sl / g.TW, rx = sl - ry * g.TW, y_c0 = t >> 7;
@@ -484,8 +508,9 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
     unsigned char *Hs_hi = t_smem8 + 2 * TX_A_BYTES;                        // [halo pixel][32 ch]
     unsigned char *Hs_lo = Hs_hi + g.HR * g.HC * TX_PITCH;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int b = blockIdx.x, tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
-    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = blockIdx.y * 64;
+    T_DECODE_TILE_CB(b, cblk);
+    const int tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
+    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = cblk * 64;
     const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nhalo = g.HR * g.HC;
     int hb[2], opix[2];
 #pragma unroll
@@ -636,8 +661,9 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
     unsigned char *Hs_hi = t_smem8 + 2 * TXW2_A_BYTES;
     unsigned char *Hs_lo = Hs_hi + g.HR * g.HC * TXW2_PITCH;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int b = blockIdx.x, tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
-    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = blockIdx.y * 64;
+    T_DECODE_TILE_CB(b, cblk);
+    const int tx = b % g.tiles_x, ty = (b / g.tiles_x) % g.tiles_y, img = b / (g.tiles_x * g.tiles_y);
+    const int y0 = ty * g.R, x0 = tx * g.TW, co0 = cblk * 64;
     const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nhalo = g.HR * g.HC;
     int hbp[4], opix[4];                        // halo pixel of the slot's top-left tap, output pixel (or -1)
 #pragma unroll
@@ -822,7 +848,8 @@ __global__ __launch_bounds__(256, 2) void tconv3_wgrad_x3_kernel(TConv c, TTileW
     unsigned char *Yh = t_smem8, *Yl = t_smem8 + 64 * TXW_YP;                   // dY tile [64 couts][128 slots]
     unsigned char *Xh = t_smem8 + 2 * 64 * TXW_YP, *Xl = Xh + TXW_CI * g.CHB;   // halo [32 channels][HR][HP]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int c0 = blockIdx.x * TXW_CI, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    T_DECODE_XYZ(bx_, by_, slice);
+    const int c0 = bx_ * TXW_CI, co0 = by_ * 64;
     const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nh = g.HR * g.HP;
     int hbq[4];                                   // byte offset (inside a channel's halo) of this lane's 8-slot group, per pixel group
 #pragma unroll
@@ -960,7 +987,8 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3pp_kernel(TConv c, TTil
     unsigned char *Yh = sbase, *Yl = sbase + 64 * TXW_YP;                       // dY tile [64 couts][128 slots]
     unsigned char *Xh = sbase + 2 * 64 * TXW_YP, *Xl = Xh + TXW_CI * g.CHB;     // halo [32 channels][HR][HP]
     const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int c0 = blockIdx.x * TXW_CI, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    T_DECODE_XYZ(bx_, by_, slice);
+    const int c0 = bx_ * TXW_CI, co0 = by_ * 64;
     const int HW = c.H * c.W, HoWo = c.Ho * c.Wo, nh = g.HR * g.HP;
     int hbq[4];                                   // byte offset (inside a channel's halo) of this lane's 8-slot group, per pixel group
 #pragma unroll
@@ -1109,6 +1137,224 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3pp_kernel(TConv c, TTil
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the ping-pong weight gradient with ONE global round trip of staging per tile.  Stamps and the step's kernel stats
+// (profiles/r05_train_step_*) said what bounds tconv3_wgrad_x3pp_kernel: not the matrix pipe (216 MFMAs = 3.5 k cycles per tile and
+// wave) but the staging group next to it -- 32 + 30 scalar dword loads per thread, the halo ones in five dependent batches of six
+// (more in flight spilled), every value split and written to LDS with 4-byte stores: ~5 memory round trips per phase against 1.6 us
+// of matrix work.  Here
+//   * dY never goes through LDS: a lane's A fragment IS eight consecutive pixels of its cout row (NCHW: 32 contiguous bytes, 16-byte
+//     aligned when the map and tile widths are multiples of 4) -- two dwordx4 loads per pixel group, prefetched into registers by the
+//     group that will multiply them in its NEXT phase, split into hi / lo right before the MFMAs;
+//   * the X halo is fetched by rows: per (channel, halo row) TW / 4 aligned dwordx4 pieces + the two edge columns, <= 9 loads per
+//     thread, ALL in flight at once (36 registers), each piece written with one 8-byte store per plane.  Layout per channel:
+//     [16 B lead][HR rows x HP bf16], element hx of a row = image column x0 + hx, the left edge column x0 - 1 in the last slot of
+//     the previous row's pitch (hx = -1): every dwordx4 piece lands 8-byte aligned, a slot group's fragment for tap kx is the
+//     aligned 16-byte group shifted by kx - 1 elements (kx = 1: as read; kx = 0 / 2: five v_alignbyte with the dword before / after).
+// Same tiles, same slices, same products in the same order as the x3pp kernel: bit-identical partial sums.  Shapes it does not take
+// (widths that are not multiples of 4, pad != 1) stay on x3pp.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TXV_NPI 9
+__global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3v_kernel(TConv c, TTileW g, float *__restrict__ partial, int tiles_per_slice, int ntiles, int ppi, int npieces) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t_smem8[];
+    const int set_bytes = 2 * TXW_CI * g.CHB;
+    const int grp = threadIdx.x >> 8;
+    unsigned char *Xh = t_smem8 + grp * set_bytes, *Xl = Xh + TXW_CI * g.CHB;       // halo [32 channels][16 + HR x HP x 2 bytes]
+    const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    T_DECODE_XYZ(bx_, by_, slice);
+    const int c0 = bx_ * TXW_CI, co0 = by_ * 64;
+    const int HW = c.H * c.W, HoWo = c.Ho * c.Wo;
+    {   // the images start as zeros: slots no piece ever writes (behind the right edge column) are READ by the fragments of the padding
+        // slots, whose dY is zero -- the product must not be 0 x NaN
+        t_u32x4 *z = reinterpret_cast<t_u32x4 *>(t_smem8);
+        for (int i = threadIdx.x; i < 2 * set_bytes / 16; i += 512) z[i] = t_u32x4{0u, 0u, 0u, 0u};
+    }
+    // this lane's four 8-slot pixel groups: halo byte offset of the aligned fragment group (tap ky adds rows), dY pixel offset in the tile
+    int hbq[4], aoff[4], arow[4], acol[4];
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+        const int s0 = 32 * pg + 8 * q, ry = s0 / g.SW, rx0 = s0 - ry * g.SW;
+        const bool in = ry < g.R;
+        hbq[pg] = 16 + ((in ? ry : 0) * g.HP + rx0) * 2;
+        arow[pg] = in ? ry : -1;
+        acol[pg] = rx0;
+        aoff[pg] = (in ? ry : 0) * c.Wo + rx0;
+    }
+    // tile-invariant description of this thread's X pieces: piece t + 256 i = (item = (channel, halo row), pc): pc 0 = left edge column,
+    // ppi - 1 = right edge column, else the dwordx4 piece of columns 4 (pc - 1) .. + 3
+    int goff[TXV_NPI], loff[TXV_NPI], meta[TXV_NPI];       // element offset from (channel c0, row y0, column x0); LDS byte offset; kind | row << 2 | ch << 8 (kind 3 = none)
+#pragma unroll
+    for (int i = 0; i < TXV_NPI; ++i) {
+        const int pidx = t + 256 * i;
+        const int item = pidx / ppi, pc = pidx - item * ppi, ch = item / g.HR, row = item - ch * g.HR;
+        const int kind = pidx < npieces ? (pc == 0 ? 0 : (pc == ppi - 1 ? 2 : 1)) : 3;
+        const int colrel = kind == 0 ? -1 : (kind == 2 ? g.TW : 4 * (pc - 1));
+        goff[i] = ch * HW + (row - 1) * c.W + colrel;
+        loff[i] = ch * g.CHB + 16 + row * g.HP * 2 + 2 * colrel;
+        meta[i] = kind | (row << 2) | (ch << 8);
+    }
+    t_f32x4 acc[2][9];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[n][k] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    t_f32x4 a4[4][2];                                     // this lane's dY fragments of the tile its group multiplies next
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) a4[pg][0] = a4[pg][1] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tbeg = slice * tiles_per_slice, tend = min(tbeg + tiles_per_slice, ntiles), ntl = tend - tbeg;
+    __syncthreads();
+    for (int ph = 0; ph <= ntl; ++ph) {
+      if ((ph & 1) == grp) {
+        if (ph < ntl) {
+            const int tile = tbeg + ph;
+            const int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, img = tile / (g.tiles_x * g.tiles_y);
+            const int y0 = ty * g.R, x0 = tx * g.TW;
+            // ---- every load of the phase first: X pieces, then the dY fragments ----
+            const float *xb = c.x + (size_t)img * c.Cin * HW + (size_t)c0 * HW + y0 * c.W + x0;
+            t_f32x4 xv[TXV_NPI];
+            unsigned okm = 0;
+#pragma unroll
+            for (int i = 0; i < TXV_NPI; ++i) {
+                const int kind = meta[i] & 3, row = (meta[i] >> 2) & 63, ch = meta[i] >> 8;
+                const int iy = y0 - 1 + row;
+                const int ok = (int)(kind != 3) & (int)(c0 + ch < c.Cin) & (int)(iy >= 0) & (int)(iy < c.H) &
+                               (int)(kind == 0 ? x0 > 0 : (kind == 2 ? x0 + g.TW < c.W : true));
+                okm |= (unsigned)ok << i;
+                xv[i] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kind == 1) xv[i] = *reinterpret_cast<const t_f32x4 *>(xb + (goff[i] & -ok));
+                else if (kind != 3) xv[i][0] = xb[goff[i] & -ok];
+            }
+            const int cout = co0 + 16 * wave + r;
+            const float *yb = c.y + ((size_t)img * c.Cout + (cout < c.Cout ? cout : 0)) * HoWo + y0 * c.Wo + x0;
+            unsigned aok = 0;
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {
+                const int rowok = (int)(cout < c.Cout) & (int)(arow[pg] >= 0) & (int)(y0 + arow[pg] < c.Ho);
+                const int ok0 = rowok & (int)(acol[pg] + 3 < g.TW), ok1 = rowok & (int)(acol[pg] + 7 < g.TW);
+                aok |= (unsigned)ok0 << (2 * pg) | (unsigned)ok1 << (2 * pg + 1);
+                a4[pg][0] = *reinterpret_cast<const t_f32x4 *>(yb + (aoff[pg] & -ok0));
+                a4[pg][1] = *reinterpret_cast<const t_f32x4 *>(yb + ((aoff[pg] + 4) & -ok1));
+            }
+            // ---- X: split and store (zeros where the piece lies outside the image / beyond Cin) ----
+#pragma unroll
+            for (int i = 0; i < TXV_NPI; ++i) {
+                const int kind = meta[i] & 3;
+                const bool ok = (okm >> i) & 1u;
+                if (kind == 1) {
+                    union { __bf16 b[4]; unsigned long long u; } ph4, pl4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = ok ? xv[i][j] : 0.f;
+                        const __bf16 h = (__bf16)v;
+                        ph4.b[j] = h;
+                        pl4.b[j] = (__bf16)(v - (float)h);
+                    }
+                    *reinterpret_cast<unsigned long long *>(Xh + loff[i]) = ph4.u;
+                    *reinterpret_cast<unsigned long long *>(Xl + loff[i]) = pl4.u;
+                } else if (kind != 3) {
+                    const float v = ok ? xv[i][0] : 0.f;
+                    const __bf16 h = (__bf16)v;
+                    *reinterpret_cast<__bf16 *>(Xh + loff[i]) = h;
+                    *reinterpret_cast<__bf16 *>(Xl + loff[i]) = (__bf16)(v - (float)h);
+                }
+            }
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {             // the masked loads fetched element 0 of the row: zero them
+                if (!((aok >> (2 * pg)) & 1u)) a4[pg][0] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!((aok >> (2 * pg + 1)) & 1u)) a4[pg][1] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+      } else if (ph >= 1) {
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+            t_bf16x8 ah, al;
+            {
+                const float v8[8] = {a4[pg][0][0], a4[pg][0][1], a4[pg][0][2], a4[pg][0][3], a4[pg][1][0], a4[pg][1][1], a4[pg][1][2], a4[pg][1][3]};
+                t_split8(v8, 0xffu, ah, al);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int bo = (16 * n + r) * g.CHB + hbq[pg] + ky * g.HP * 2;
+                    const t_u32x4 vh = *reinterpret_cast<const t_u32x4 *>(Xh + bo), vl = *reinterpret_cast<const t_u32x4 *>(Xl + bo);
+                    const unsigned mh = *reinterpret_cast<const unsigned *>(Xh + bo - 4), ml = *reinterpret_cast<const unsigned *>(Xl + bo - 4);
+                    const unsigned nh4 = *reinterpret_cast<const unsigned *>(Xh + bo + 16), nl4 = *reinterpret_cast<const unsigned *>(Xl + bo + 16);
+                    const unsigned sh1 = __builtin_amdgcn_alignbyte(vh[1], vh[0], 2), sh2 = __builtin_amdgcn_alignbyte(vh[2], vh[1], 2), sh3 = __builtin_amdgcn_alignbyte(vh[3], vh[2], 2);
+                    const unsigned sl1 = __builtin_amdgcn_alignbyte(vl[1], vl[0], 2), sl2 = __builtin_amdgcn_alignbyte(vl[2], vl[1], 2), sl3 = __builtin_amdgcn_alignbyte(vl[3], vl[2], 2);
+                    t_bf16x8 bh[3], bl[3];
+                    bh[0] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vh[0], mh, 2), sh1, sh2, sh3});
+                    bl[0] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vl[0], ml, 2), sl1, sl2, sl3});
+                    bh[1] = t_as_bf16x8(vh);
+                    bl[1] = t_as_bf16x8(vl);
+                    bh[2] = t_as_bf16x8(t_u32x4{sh1, sh2, sh3, __builtin_amdgcn_alignbyte(nh4, vh[3], 2)});
+                    bl[2] = t_as_bf16x8(t_u32x4{sl1, sl2, sl3, __builtin_amdgcn_alignbyte(nl4, vl[3], 2)});
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+        }
+      }
+      __syncthreads();
+    }
+    // add the two groups' accumulators through LDS (72 floats per thread, the image sets are free now)
+    float *scr = reinterpret_cast<float *>(t_smem8);
+    if (grp == 1) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int k9 = 0; k9 < 9; ++k9)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) scr[((n * 9 + k9) * 4 + i) * 256 + t] = acc[n][k9][i];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int k9 = 0; k9 < 9; ++k9)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[n][k9][i] += scr[((n * 9 + k9) * 4 + i) * 256 + t];
+    float *pb = partial + (size_t)slice * c.Cout * c.Kdim;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int ci = c0 + 16 * n + r;
+        if (ci >= c.Cin) continue;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * wave + 4 * q + i;
+                if (co < c.Cout) pb[((size_t)co * c.Cin + ci) * 9 + tap] = acc[n][tap][i];
+            }
+    }
+}
+
+// geometry of the vectorised variant: the x3pp tiles, the row layout described above; false = the shape stays on x3pp
+static bool t_tile_geometry_wx3v(const TConv &c, TTileW *g, int *ppi, int *npieces) {
+    if (c.pad != 1 || c.Ho != c.H || c.Wo != c.W || (c.W & 3)) return false;
+    g->tiles_x = (c.Wo + 63) / 64;
+    if (c.Wo % g->tiles_x) return false;
+    g->TW = c.Wo / g->tiles_x;
+    if (g->TW & 3) return false;
+    g->SW = (g->TW + 7) / 8 * 8;
+    g->R = 128 / g->SW;
+    if (g->R > c.Ho) g->R = c.Ho;
+    if (g->R < 1) return false;
+    g->tiles_y = (c.Ho + g->R - 1) / g->R;
+    g->HP = g->SW + 8;
+    g->HR = g->R + 2;
+    g->CHB = 16 + g->HR * g->HP * 2;
+    *ppi = g->TW / 4 + 2;
+    *npieces = TXW_CI * g->HR * *ppi;
+    if (g->HR > 63 || *npieces > 256 * TXV_NPI) return false;
+    const size_t sets = (size_t)2 * 2 * TXW_CI * g->CHB;
+    return sets <= 158 * 1024;                              // (the launch asks for at least the 72 KB the accumulator hand-over at the end needs)
+}
+
 static bool t_tile_geometry_wx3(int Ho, int Wo, TTileW *g) {
     g->tiles_x = (Wo + 63) / 64;
     g->TW = (Wo + g->tiles_x - 1) / g->tiles_x;
@@ -1132,6 +1378,7 @@ static int t_tile_lds_ok(pn_ctx *ctx) {       // the tile kernels use up to 76 K
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_tile_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_x3pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PN_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)tconv3_wgrad_x3v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         done = true;
     }
     return PN_OK;
@@ -1175,7 +1422,8 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
     __shared__ float As[TW_RC][TW_P];      // dY  [pixel][cout]
     __shared__ float Bs[TW_RC][TW_P];      // X   [pixel][k column]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
-    const int kc0 = blockIdx.x * 64, co0 = blockIdx.y * 64, slice = blockIdx.z;
+    T_DECODE_XYZ(bx_, by_, slice);
+    const int kc0 = bx_ * 64, co0 = by_ * 64;
     const int HoWo = c.Ho * c.Wo;
     const int pl = t & 31, g = t >> 5;
     int kci[8], kky[8], kkx[8];
@@ -1855,7 +2103,14 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
         hipStream_t s = (hipStream_t)hip_stream;
         bool done = false;
         if (x3) {
-            if (pp) {
+            TTileW gv;
+            int ppi = 0, npieces = 0;
+            if (pp && !getenv("POPNET_TRAIN_WGRAD_NOVEC") && t_tile_geometry_wx3v(c, &gv, &ppi, &npieces) && gv.tiles_x == gw.tiles_x && gv.tiles_y == gw.tiles_y && gv.R == gw.R && gv.TW == gw.TW) {
+                // the same tiles and slices as x3pp (bit-identical partial sums), one round trip of staging per tile
+                const size_t lds = std::max<size_t>((size_t)2 * 2 * TXW_CI * gv.CHB, (size_t)72 * 256 * 4);
+                hipLaunchKernelGGL(tconv3_wgrad_x3v_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S3), dim3(512), lds, s, c, gv, (float *)ws, tps3, nt, ppi, npieces);
+                t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, S3);
+            } else if (pp) {
                 hipLaunchKernelGGL(tconv3_wgrad_x3pp_kernel, dim3((unsigned)((Cin + TXW_CI - 1) / TXW_CI), (unsigned)((Cout + 63) / 64), (unsigned)S3), dim3(512), 2 * setb, s, c, gw, (float *)ws, tps3, nt);
                 t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, S3);
             } else {

@@ -93,6 +93,39 @@ def test_conv_forward_dgrad_wgrad_vs_torch(gpu, shape, prec, monkeypatch):
         assert _rel(dx, 2 * xr.grad) < TOL
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 28, 28, 128), (4, 256, 28, 28, 256), (4, 64, 56, 56, 64), (2, 64, 112, 112, 64), (6, 187, 28, 28, 128),
+                                   (3, 96, 30, 20, 72), (2, 64, 27, 40, 64), (1, 32, 9, 64, 64)])
+def test_vectorised_weight_gradient_equals_the_ping_pong_kernel_bit_for_bit(gpu, shape, monkeypatch):
+    """Round 5: tconv3_wgrad_x3v_kernel (dY fragments straight from global memory, the X halo fetched by rows with 16-byte loads, one
+    memory round trip of staging per tile) walks the same tiles and slices and issues the same MFMAs in the same order as
+    tconv3_wgrad_x3pp_kernel (POPNET_TRAIN_WGRAD_NOVEC=1): identical weight gradients, bit for bit, on the network's map sizes, ragged
+    channel counts, partial last row tiles and the narrowest / widest tile widths -- and within the split-bf16 tolerance of autograd."""
+    from popnet_amd import _lib
+    N, Cin, H, W, Cout = shape
+    L, ctx = _lib.lib(), _lib.Context(0)
+    ctx.check(L.pn_train_set_precision(ctx.handle, _lib.PN_PREC_BF16X3), "precision")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)).requires_grad_()
+    yr = F.conv2d(x, w, None, 1, 1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd, dyd = x.to(gpu), dy.to(gpu)
+    s = _lib.current_stream_ptr(torch.device(gpu))
+    out = []
+    for novec in (False, True):
+        if novec:
+            monkeypatch.setenv("POPNET_TRAIN_WGRAD_NOVEC", "1")          # read at every call
+        dw = torch.zeros((Cout, Cin, 3, 3), device=gpu)
+        ctx.check(L.pn_conv2d_wgrad(ctx.handle, _p(xd), _p(dyd), _p(dw), None, N, Cin, H, W, Cout, 3, 1, 1, s), "wgrad")
+        out.append(dw.clone())
+    monkeypatch.delenv("POPNET_TRAIN_WGRAD_NOVEC")
+    ctx.check(L.pn_train_set_precision(ctx.handle, 0), "precision")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]).all() and torch.equal(out[0], out[1])
+    assert _rel(out[0], w.grad) < 1e-4, _rel(out[0], w.grad)
+
+
 @pytest.mark.parametrize("hw", [(13, 9), (12, 8)])       # odd map: scalar kernels; H * W a multiple of 4: the 16-byte variants
 @pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (1, True), (2, False)])
 def test_bn_train_forward_backward_vs_torch(gpu, act, with_res, hw):
