@@ -541,6 +541,21 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
 
+    t_u32x4 wv[6];                                     // the NEXT (chunk, kernel row) step's weight pieces of this thread
+    auto load_w = [&](int wc0, int wky) {
+        const __bf16 *wrow = wpx + ((size_t)(wc0 >> 5) * 9 + wky * 3) * c.Cout * 32;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int piece = t + 256 * j;                    // < 1536: plane, kx, cout, segment
+            const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
+            const int ok = (int)(co0 + co < c.Cout);
+            const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
+            wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
+            if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    load_w(0, 0);
+
     for (int c0 = 0; c0 < c.Cin; c0 += 32) {
         const int cbase = c0 + 8 * wave;
         unsigned cmask = 0;
@@ -573,18 +588,9 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
             }
         }
         for (int ky = 0; ky < 3; ++ky) {
-            // ---- weight slice of kernel row ky: [3 taps][64 couts][32 ch], straight 16-byte copies of the packed planes ----
-            t_u32x4 wv[6];
-            const __bf16 *wrow = wpx + ((size_t)(c0 >> 5) * 9 + ky * 3) * c.Cout * 32;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int piece = t + 256 * j;                    // < 1536: plane, kx, cout, segment
-                const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
-                const int ok = (int)(co0 + co < c.Cout);
-                const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
-                wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
-                if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
-            }
+            // ---- weight slice of kernel row ky: [3 taps][64 couts][32 ch], straight 16-byte copies of the packed planes; fetched one
+            // (chunk, kernel row) step AHEAD (round 5): the loads of the next step are in flight under this step's MFMAs instead of in
+            // front of them -- three of a chunk's five exposed memory round trips gone ----
             if (ky) __syncthreads();                  // the previous kernel row's fragments have been read
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -593,6 +599,8 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
                 *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + (kx * 64 + co) * TX_PITCH + 16 * seg) = wv[j];
             }
             __syncthreads();
+            if (ky < 2) load_w(c0, ky + 1);
+            else if (c0 + 32 < c.Cin) load_w(c0 + 32, 0);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int toff = (ky * g.HC + kx) * TX_PITCH;
@@ -692,6 +700,21 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = t_f32x4{0.f, 0.f, 0.f, 0.f};
 
+    t_u32x4 wv[6];                                     // the NEXT (chunk, kernel row) step's weight pieces of this thread
+    auto load_w = [&](int wc0, int wky) {
+        const __bf16 *wrow = wpx + ((size_t)(wc0 >> 5) * 9 + wky * 3) * c.Cout * 32;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int piece = t + 256 * j;
+            const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
+            const int ok = (int)(co0 + co < c.Cout);
+            const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
+            wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
+            if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    load_w(0, 0);
+
     for (int c0 = 0; c0 < c.Cin; c0 += 32) {
         const int cbase = c0 + 8 * wave;
         unsigned cmask = 0;
@@ -722,17 +745,6 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
         }
 #pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
-            t_u32x4 wv[6];
-            const __bf16 *wrow = wpx + ((size_t)(c0 >> 5) * 9 + ky * 3) * c.Cout * 32;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int piece = t + 256 * j;
-                const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
-                const int ok = (int)(co0 + co < c.Cout);
-                const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
-                wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
-                if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
-            }
             if (ky) __syncthreads();
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -741,6 +753,8 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
                 *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + t_swz(kx * 64 + co, seg)) = wv[j];
             }
             __syncthreads();
+            if (ky < 2) load_w(c0, ky + 1);           // the next step's weights, in flight under this step's MFMAs (see tconv3_tile_x3_kernel)
+            else if (c0 + 32 < c.Cin) load_w(c0 + 32, 0);
 #pragma unroll 1
             for (int kx = 0; kx < 3; ++kx) {          // not unrolled: with three taps' fragments hoisted the kernel spills (124 B / lane)
                 t_bf16x8 bh[4], bl[4];
@@ -1182,16 +1196,14 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3v_kernel(TConv c, TTile
     }
     // tile-invariant description of this thread's X pieces: piece t + 256 i = (item = (channel, halo row), pc): pc 0 = left edge column,
     // ppi - 1 = right edge column, else the dwordx4 piece of columns 4 (pc - 1) .. + 3
-    int goff[TXV_NPI], loff[TXV_NPI], meta[TXV_NPI];       // element offset from (channel c0, row y0, column x0); LDS byte offset; kind | row << 2 | ch << 8 (kind 3 = none)
+    int meta[TXV_NPI];                                   // kind | row << 2 | ch << 8 | (colrel + 1) << 14 (kind 3 = none); offsets are rebuilt from it per tile
 #pragma unroll
     for (int i = 0; i < TXV_NPI; ++i) {
         const int pidx = t + 256 * i;
         const int item = pidx / ppi, pc = pidx - item * ppi, ch = item / g.HR, row = item - ch * g.HR;
         const int kind = pidx < npieces ? (pc == 0 ? 0 : (pc == ppi - 1 ? 2 : 1)) : 3;
         const int colrel = kind == 0 ? -1 : (kind == 2 ? g.TW : 4 * (pc - 1));
-        goff[i] = ch * HW + (row - 1) * c.W + colrel;
-        loff[i] = ch * g.CHB + 16 + row * g.HP * 2 + 2 * colrel;
-        meta[i] = kind | (row << 2) | (ch << 8);
+        meta[i] = kind | (row << 2) | (ch << 8) | ((colrel + 1) << 14);
     }
     t_f32x4 acc[2][9];
 #pragma unroll
@@ -1205,7 +1217,11 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3v_kernel(TConv c, TTile
     __syncthreads();
     for (int ph = 0; ph <= ntl; ++ph) {
       if ((ph & 1) == grp) {
+#ifdef TXV_FAKE_NOSTAGE
+        if (ph < 2) {
+#else
         if (ph < ntl) {
+#endif
             const int tile = tbeg + ph;
             const int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, img = tile / (g.tiles_x * g.tiles_y);
             const int y0 = ty * g.R, x0 = tx * g.TW;
@@ -1215,14 +1231,16 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3v_kernel(TConv c, TTile
             unsigned okm = 0;
 #pragma unroll
             for (int i = 0; i < TXV_NPI; ++i) {
-                const int kind = meta[i] & 3, row = (meta[i] >> 2) & 63, ch = meta[i] >> 8;
+                const int kind = meta[i] & 3, row = (meta[i] >> 2) & 63, ch = (meta[i] >> 8) & 63, colrel = (meta[i] >> 14) - 1;
+                // every piece is ONE kind of load, a 16-byte group (the edge columns too: the group that holds column x0 - 1 / x0 + TW, one element
+                // of it used): a dword load and a dwordx4 load into the same registers on two divergent paths made the compiler wait for each
+                // piece before issuing the next -- nine dependent round trips per phase instead of one
+                const int goff_i = ch * HW + (row - 1) * c.W + (kind == 0 ? -4 : colrel);
                 const int iy = y0 - 1 + row;
                 const int ok = (int)(kind != 3) & (int)(c0 + ch < c.Cin) & (int)(iy >= 0) & (int)(iy < c.H) &
                                (int)(kind == 0 ? x0 > 0 : (kind == 2 ? x0 + g.TW < c.W : true));
                 okm |= (unsigned)ok << i;
-                xv[i] = t_f32x4{0.f, 0.f, 0.f, 0.f};
-                if (kind == 1) xv[i] = *reinterpret_cast<const t_f32x4 *>(xb + (goff[i] & -ok));
-                else if (kind != 3) xv[i][0] = xb[goff[i] & -ok];
+                xv[i] = *reinterpret_cast<const t_f32x4 *>(xb + (goff_i & -ok));
             }
             const int cout = co0 + 16 * wave + r;
             const float *yb = c.y + ((size_t)img * c.Cout + (cout < c.Cout ? cout : 0)) * HoWo + y0 * c.Wo + x0;
@@ -1240,6 +1258,7 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3v_kernel(TConv c, TTile
             for (int i = 0; i < TXV_NPI; ++i) {
                 const int kind = meta[i] & 3;
                 const bool ok = (okm >> i) & 1u;
+                const int loff_i = ((meta[i] >> 8) & 63) * g.CHB + 16 + ((meta[i] >> 2) & 63) * g.HP * 2 + 2 * ((meta[i] >> 14) - 1);
                 if (kind == 1) {
                     union { __bf16 b[4]; unsigned long long u; } ph4, pl4;
 #pragma unroll
@@ -1249,13 +1268,13 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3v_kernel(TConv c, TTile
                         ph4.b[j] = h;
                         pl4.b[j] = (__bf16)(v - (float)h);
                     }
-                    *reinterpret_cast<unsigned long long *>(Xh + loff[i]) = ph4.u;
-                    *reinterpret_cast<unsigned long long *>(Xl + loff[i]) = pl4.u;
+                    *reinterpret_cast<unsigned long long *>(Xh + loff_i) = ph4.u;
+                    *reinterpret_cast<unsigned long long *>(Xl + loff_i) = pl4.u;
                 } else if (kind != 3) {
-                    const float v = ok ? xv[i][0] : 0.f;
+                    const float v = ok ? (kind == 0 ? xv[i][3] : xv[i][0]) : 0.f;
                     const __bf16 h = (__bf16)v;
-                    *reinterpret_cast<__bf16 *>(Xh + loff[i]) = h;
-                    *reinterpret_cast<__bf16 *>(Xl + loff[i]) = (__bf16)(v - (float)h);
+                    *reinterpret_cast<__bf16 *>(Xh + loff_i) = h;
+                    *reinterpret_cast<__bf16 *>(Xl + loff_i) = (__bf16)(v - (float)h);
                 }
             }
 #pragma unroll
@@ -1265,38 +1284,54 @@ __global__ __launch_bounds__(512, 1) void tconv3_wgrad_x3v_kernel(TConv c, TTile
             }
         }
       } else if (ph >= 1) {
+#ifndef TXV_FAKE_NOMFMA                          // timing-only ablations (wrong results): -DTXV_FAKE_NOMFMA / -DTXV_FAKE_NOSTAGE, variant builds of scripts/r05
+        // 24 items (pixel group pg, channel tile n, kernel row ky), 9 MFMAs each.  Software-pipelined by hand: the six LDS reads of item
+        // it + 1 are issued before the MFMAs of item it (the compiler's own schedule waited for every item's reads right before its
+        // MFMAs and separated the dependent triple of an accumulator with s_nop: 45 % matrix-pipe use inside this section), and the three
+        // products of a tap are interleaved across the three taps of the row, so that no MFMA reads the accumulator the previous one
+        // writes.  Per accumulator the order is still hi*hi, hi*lo, lo*hi: the sums are bit-identical.
+        struct Frag { t_u32x4 vh, vl; unsigned mh, ml, nh, nl; };
+        auto load_frag = [&](int it) -> Frag {
+            const int pg = it / 6, n = (it % 6) / 3, ky = it % 3;
+            const int bo = (16 * n + r) * g.CHB + hbq[pg] + ky * g.HP * 2;
+            Frag f;
+            f.vh = *reinterpret_cast<const t_u32x4 *>(Xh + bo); f.vl = *reinterpret_cast<const t_u32x4 *>(Xl + bo);
+            f.mh = *reinterpret_cast<const unsigned *>(Xh + bo - 4); f.ml = *reinterpret_cast<const unsigned *>(Xl + bo - 4);
+            f.nh = *reinterpret_cast<const unsigned *>(Xh + bo + 16); f.nl = *reinterpret_cast<const unsigned *>(Xl + bo + 16);
+            return f;
+        };
+        Frag fr[2];
+        fr[0] = load_frag(0);
+        t_bf16x8 ah, al;
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg) {
-            t_bf16x8 ah, al;
-            {
+        for (int it = 0; it < 24; ++it) {
+            const int pg = it / 6, n = (it % 6) / 3, ky = it % 3;
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < 24) fr[(it + 1) & 1] = load_frag(it + 1);
+            if (it % 6 == 0) {
                 const float v8[8] = {a4[pg][0][0], a4[pg][0][1], a4[pg][0][2], a4[pg][0][3], a4[pg][1][0], a4[pg][1][1], a4[pg][1][2], a4[pg][1][3]};
                 t_split8(v8, 0xffu, ah, al);
             }
+            const Frag &f = fr[it & 1];
+            const unsigned sh1 = __builtin_amdgcn_alignbyte(f.vh[1], f.vh[0], 2), sh2 = __builtin_amdgcn_alignbyte(f.vh[2], f.vh[1], 2), sh3 = __builtin_amdgcn_alignbyte(f.vh[3], f.vh[2], 2);
+            const unsigned sl1 = __builtin_amdgcn_alignbyte(f.vl[1], f.vl[0], 2), sl2 = __builtin_amdgcn_alignbyte(f.vl[2], f.vl[1], 2), sl3 = __builtin_amdgcn_alignbyte(f.vl[3], f.vl[2], 2);
+            t_bf16x8 bh[3], bl[3];
+            bh[0] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(f.vh[0], f.mh, 2), sh1, sh2, sh3});
+            bl[0] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(f.vl[0], f.ml, 2), sl1, sl2, sl3});
+            bh[1] = t_as_bf16x8(f.vh);
+            bl[1] = t_as_bf16x8(f.vl);
+            bh[2] = t_as_bf16x8(t_u32x4{sh1, sh2, sh3, __builtin_amdgcn_alignbyte(f.nh, f.vh[3], 2)});
+            bl[2] = t_as_bf16x8(t_u32x4{sl1, sl2, sl3, __builtin_amdgcn_alignbyte(f.nl, f.vl[3], 2)});
+            __builtin_amdgcn_sched_barrier(0);          // (left to the compiler the fragment arithmetic lands between the MFMAs and the section is 6 % slower)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int kx = 0; kx < 3; ++kx) acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int bo = (16 * n + r) * g.CHB + hbq[pg] + ky * g.HP * 2;
-                    const t_u32x4 vh = *reinterpret_cast<const t_u32x4 *>(Xh + bo), vl = *reinterpret_cast<const t_u32x4 *>(Xl + bo);
-                    const unsigned mh = *reinterpret_cast<const unsigned *>(Xh + bo - 4), ml = *reinterpret_cast<const unsigned *>(Xl + bo - 4);
-                    const unsigned nh4 = *reinterpret_cast<const unsigned *>(Xh + bo + 16), nl4 = *reinterpret_cast<const unsigned *>(Xl + bo + 16);
-                    const unsigned sh1 = __builtin_amdgcn_alignbyte(vh[1], vh[0], 2), sh2 = __builtin_amdgcn_alignbyte(vh[2], vh[1], 2), sh3 = __builtin_amdgcn_alignbyte(vh[3], vh[2], 2);
-                    const unsigned sl1 = __builtin_amdgcn_alignbyte(vl[1], vl[0], 2), sl2 = __builtin_amdgcn_alignbyte(vl[2], vl[1], 2), sl3 = __builtin_amdgcn_alignbyte(vl[3], vl[2], 2);
-                    t_bf16x8 bh[3], bl[3];
-                    bh[0] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vh[0], mh, 2), sh1, sh2, sh3});
-                    bl[0] = t_as_bf16x8(t_u32x4{__builtin_amdgcn_alignbyte(vl[0], ml, 2), sl1, sl2, sl3});
-                    bh[1] = t_as_bf16x8(vh);
-                    bl[1] = t_as_bf16x8(vl);
-                    bh[2] = t_as_bf16x8(t_u32x4{sh1, sh2, sh3, __builtin_amdgcn_alignbyte(nh4, vh[3], 2)});
-                    bl[2] = t_as_bf16x8(t_u32x4{sl1, sl2, sl3, __builtin_amdgcn_alignbyte(nl4, vl[3], 2)});
+            for (int kx = 0; kx < 3; ++kx) acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[kx], acc[n][ky * 3 + kx], 0, 0, 0);
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
-                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[kx], acc[n][ky * 3 + kx], 0, 0, 0);
-                        acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
-                    }
-                }
+            for (int kx = 0; kx < 3; ++kx) acc[n][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[kx], acc[n][ky * 3 + kx], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       __syncthreads();
     }
