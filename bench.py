@@ -579,7 +579,7 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
         post_bytes = BATCH * ((185024 if net == "rtpose" else 100 * 14 * 14 * 4) + witem)
         dom = kernels[0] if kernels else {"kernel": "none", "us_per_step": 0.0, "avg_launch_us": 0.0, "tflops": 0.0, "flops_per_launch": 0.0, "launches_per_step": 0}
         # HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside an un-profiled run: the figure
-        # comes from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (scripts/r04/pmc_traffic.sh ->
+        # comes from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (scripts/r05/profiles.sh ->
         # scripts/make_traffic_json.py) and is labelled with where and when it was measured -- `traffic_source` -- so nobody
         # reads a stored constant as part of this run (VERDICT r03 item 3 ii)
         traffic, traffic_source = None, None

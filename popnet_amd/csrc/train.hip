@@ -729,7 +729,12 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
             for (int i = I0[half]; i < I1[half]; ++i) {
                 const int okp = (int)(hoff[i] >= 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) hv[i - I0[half]][j] = xb[((cbase + j) * HW + hoff[i]) & -(okp & (int)((cmask >> j) & 1u))];
+                for (int j = 0; j < 8; ++j)
+#ifdef TXW2_FAKE_NOHALO                      // timing-only ablations (wrong results): -DTXW2_FAKE_NOHALO / _NOMFMA, variant builds of scripts/r05
+                    hv[i - I0[half]][j] = 1.f + (float)okp;
+#else
+                    hv[i - I0[half]][j] = xb[((cbase + j) * HW + hoff[i]) & -(okp & (int)((cmask >> j) & 1u))];
+#endif
             }
             if (half == 0) __syncthreads();       // the previous chunk's last kernel row has been consumed
 #pragma unroll
@@ -771,9 +776,13 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
                     const t_bf16x8 al = *reinterpret_cast<const t_bf16x8 *>(As_lo + ao);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
+#ifndef TXW2_FAKE_NOMFMA
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+#else
+                        acc[m][n][0] += (float)ah[0] * (float)bh[n][0] + (float)al[1] * (float)bl[n][1];
+#endif
                     }
                 }
             }
