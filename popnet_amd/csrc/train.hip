@@ -550,8 +550,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
             const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
             const int ok = (int)(co0 + co < c.Cout);
             const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
-            wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
-            if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
+            wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);       // (rows beyond Cout read row 0: zeroed when the piece is stored -- a select here would wait for the load)
         }
     };
     load_w(0, 0);
@@ -596,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
             for (int j = 0; j < 6; ++j) {
                 const int piece = t + 256 * j;
                 const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
-                *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + (kx * 64 + co) * TX_PITCH + 16 * seg) = wv[j];
+                *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + (kx * 64 + co) * TX_PITCH + 16 * seg) = co0 + co < c.Cout ? wv[j] : t_u32x4{0u, 0u, 0u, 0u};
             }
             __syncthreads();
             if (ky < 2) load_w(c0, ky + 1);
@@ -709,8 +708,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
             const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
             const int ok = (int)(co0 + co < c.Cout);
             const size_t off = ((size_t)pl * wplane + ((size_t)kx * c.Cout + (size_t)((co0 + co) & -ok)) * 32 + seg * 8);
-            wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);
-            if (!ok) wv[j] = t_u32x4{0u, 0u, 0u, 0u};
+            wv[j] = *reinterpret_cast<const t_u32x4 *>(wrow + off);       // (rows beyond Cout read row 0: zeroed when the piece is stored -- a select here would wait for the load)
         }
     };
     load_w(0, 0);
@@ -755,7 +753,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
             for (int j = 0; j < 6; ++j) {
                 const int piece = t + 256 * j;
                 const int pl = piece / 768, rem = piece - pl * 768, kx = rem >> 8, co = (rem >> 2) & 63, seg = rem & 3;
-                *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + t_swz(kx * 64 + co, seg)) = wv[j];
+                *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + t_swz(kx * 64 + co, seg)) = co0 + co < c.Cout ? wv[j] : t_u32x4{0u, 0u, 0u, 0u};
             }
             __syncthreads();
             if (ky < 2) load_w(c0, ky + 1);           // the next step's weights, in flight under this step's MFMAs (see tconv3_tile_x3_kernel)
@@ -1392,6 +1390,7 @@ static bool t_tile_geometry_wx3v(const TConv &c, TTileW *g, int *ppi, int *npiec
     g->HP = g->SW + 8;
     g->HR = g->R + 2;
     g->CHB = 16 + g->HR * g->HP * 2;
+    if (const char *e = getenv("POPNET_TXV_CHBPAD")) g->CHB += atoi(e) & ~15;       // experiment: channel stride of the LDS images (bank mapping of the fragment reads)
     *ppi = g->TW / 4 + 2;
     *npieces = TXW_CI * g->HR * *ppi;
     if (g->HR > 63 || *npieces > 256 * TXV_NPI) return false;

@@ -158,4 +158,4 @@ def test_fp32_engine_vs_cpu_oracle_noise_class(gpu):
         n = int(recs[b]["n_persons"])
         same += int(n == ra.shape[0] and int(recs[b]["n_peaks"]) == len(ref["joint_list"]) and np.array_equal(recs[b]["person_joint"][:n], ra[:, :15].astype(np.int32)))
     print("fp32 engine vs CPU oracle: max map difference %.3g, identical assignment in %d of 24 frames" % (dmap, same))
-    assert dmap < 2e-4 and same >= 21
+    assert dmap < 2e-4 and same >= 23          # measured: 24 of 24 (r05), pinned to that count - 1
