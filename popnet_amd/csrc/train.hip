@@ -1390,7 +1390,7 @@ static bool t_tile_geometry_wx3v(const TConv &c, TTileW *g, int *ppi, int *npiec
     g->HP = g->SW + 8;
     g->HR = g->R + 2;
     g->CHB = 16 + g->HR * g->HP * 2;
-    if (const char *e = getenv("POPNET_TXV_CHBPAD")) g->CHB += atoi(e) & ~15;       // experiment: channel stride of the LDS images (bank mapping of the fragment reads)
+    // (channel stride 496 / 528 B: a sweep of + 0 .. 128 B found no faster mapping of the fragment reads onto the banks, a multiple of 256 B twice as slow: profiles/r05_notes.txt)
     *ppi = g->TW / 4 + 2;
     *npieces = TXW_CI * g->HR * *ppi;
     if (g->HR > 63 || *npieces > 256 * TXV_NPI) return false;
