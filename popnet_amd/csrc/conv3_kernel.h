@@ -31,9 +31,12 @@
 #ifndef PN_CONV3_FAST_EPILOGUE
 #define PN_CONV3_FAST_EPILOGUE 2  // wave-uniform fast epilogue: 0 never, 1 every instantiation, 2 the 128-cout blocks only (profiles/README.md v23)
 #endif
-#ifndef PN_CONV3_PIECEMAJOR
+#if !defined(PN_CONV3_PIECEMAJOR) && !defined(PN_CONV3_QUARTERMAJOR)
 #define PN_CONV3_HALFMAJOR 1      // LDS halo layout, see the header comment; -DPN_CONV3_PIECEMAJOR selects the first layout (experiments)
 #endif
+// -DPN_CONV3_QUARTERMAJOR (round 5): conv4_kernel's image, [4 planes of 16 channels][halo row][32 px][32 B] -- the 16 lanes of a
+// ds_read_b128 phase cover one whole 256-byte bank row (no conflict; the half-major image: 2-way), one DMA instruction = one 32-pixel halo row of a plane
+// (32 segments of 32 B instead of 16 of 64 B).  Measured: profiles/r05_notes.txt.
 
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_dst, lds_dst + 1024).
 // M0 is written in the same statement that uses it (the compiler does not preserve it around asm).
@@ -167,7 +170,15 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
     auto stage_one = [&](int chunk, int j, int bufoff, bool live) {   // j-th DMA instruction of this wave for `chunk`
         const int n = wave * NGW + j;                    // wave-uniform
         const bool on = live && n < NG;
-#ifdef PN_CONV3_HALFMAJOR
+#if defined(PN_CONV3_QUARTERMAJOR)
+        const int pln = n / HR, rr = n - pln * HR;          // plane of 16 channels, halo row
+        const int px = lane >> 1;
+        const int iy = iy0 + rr;
+        const bool inb = (int)on & (int)(px < HC) & (int)((unsigned)(ix0 + px) < (unsigned)P.W) & (int)((unsigned)iy < (unsigned)Hin);
+        unsigned off = (unsigned)(iy * row_b + (ix0 + px) * col_b + pln * 32 + (lane & 1) * 16);
+        const int pc = 0, i = 0;
+        const int dst_hm = pln * (IMG / 4) + rr * (PITCH * 32);
+#elif defined(PN_CONV3_HALFMAJOR)
         // half-major image [2 halves][halo row][32 px][4 pieces x 16 B]: one instruction = 16 pixels x 64 contiguous bytes
         // (4 adjacent lanes = one 64-B segment of a pixel line) instead of 64 pixels x 16 B
         const int hh = n / (2 * HR), rr = (n - hh * 2 * HR) >> 1, gg = n & 1;
@@ -192,7 +203,7 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
         const unsigned zrel = zero_rel - (unsigned)(csrc * 128);
 #ifndef PN_CONV3_FAKE_NODMA                               // timing experiment (wrong results): no halo fetch at all
         pn_glds16(img + csrc * 128 + (inb ? off : zrel),
-#ifdef PN_CONV3_HALFMAJOR
+#if defined(PN_CONV3_HALFMAJOR) || defined(PN_CONV3_QUARTERMAJOR)
                   (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + dst_hm : (NBUF >= 3 ? nchunks : NBUF) * IMG));
 #else
                   (unsigned)__builtin_amdgcn_readfirstlane(on ? bufoff + pc * PS + i * (2 * PITCH * 16) + dst_hm : (NBUF >= 3 ? nchunks : NBUF) * IMG));
@@ -215,7 +226,9 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
         int s = slot < npix ? slot : 0;
         int ry = (int)(((float)s + 0.5f) * inv_wc);
         int rx = s - ry * Wc;
-#ifdef PN_CONV3_HALFMAJOR
+#if defined(PN_CONV3_QUARTERMAJOR)
+        baddr[pt] = (q >> 1) * (IMG / 4) + (q & 1) * 16 + (ry * PITCH + rx) * 32;
+#elif defined(PN_CONV3_HALFMAJOR)
         baddr[pt] = q * 16 + (ry * PITCH + rx) * 64;
 #else
         baddr[pt] = q * PS + (ry * PITCH + rx) * 16;
@@ -248,7 +261,9 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
             if (NBUF == 2 && more) stage(chunk + 1, nxt);
         } else {
         // item j = (k-step s = half * KK + tap, pixel tile pt)
-#ifdef PN_CONV3_HALFMAJOR
+#if defined(PN_CONV3_QUARTERMAJOR)
+#define PN3_OFF(j) ((((j) / PT) / KK) * (IMG / 2) + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 32)
+#elif defined(PN_CONV3_HALFMAJOR)
 #define PN3_OFF(j) ((((j) / PT) / KK) * (IMG / 2) + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 64)
 #else
 #define PN3_OFF(j) ((((j) / PT) / KK) * 4 * PS + (((((j) / PT) % KK) / KS) * PITCH + ((((j) / PT) % KK) % KS)) * 16)
@@ -568,7 +583,12 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
             }
         }
     };
-#if defined(PN_CONV3_HALFMAJOR)
+#if defined(PN_CONV3_HALFMAJOR) || defined(PN_CONV3_QUARTERMAJOR)
+#if defined(PN_CONV3_QUARTERMAJOR)
+#define PN3_PIXOF(ba) (((unsigned)(ba) - (unsigned)((q >> 1) * (IMG / 4))) >> 5)
+#else
+#define PN3_PIXOF(ba) ((unsigned)(ba) >> 6)
+#endif
     // Fast path, chosen per WAVE (every condition is wave-uniform, so no exec-mask branching): all 32 couts of the wave
     // exist, NHWC output only, a compile-time activation.  The pixel of a slot is recovered from its LDS read address
     // (baddr = q*16 + (ry*32 + rx)*64) instead of being divided out again; same arithmetic on the values as `finish`,
@@ -589,7 +609,7 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
         if (RES) {
 #pragma clang loop unroll(full)
             for (int pt = 0; pt < PT; ++pt) {
-                const unsigned t = (unsigned)ba[pt] >> 6;
+                const unsigned t = PN3_PIXOF(ba[pt]);
                 const unsigned opix = (unsigned)pix0 + (t >> 5) * (unsigned)Wo + (t & 31u);
                 rq[pt] = *reinterpret_cast<const PN_GLOBAL u32x4 *>(rb + (opix * (unsigned)res_cs + lane_c));
             }
@@ -597,7 +617,7 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
 #pragma clang loop unroll(full)
         for (int pt = 0; pt < PT; ++pt) {
             const int slot = (wp * PT + pt) * 16 + c;
-            const unsigned t = (unsigned)ba[pt] >> 6;
+            const unsigned t = PN3_PIXOF(ba[pt]);
             const unsigned opix = (unsigned)pix0 + (t >> 5) * (unsigned)Wo + (t & 31u);
             float v[LC];
 #pragma unroll
