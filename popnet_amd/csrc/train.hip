@@ -1550,7 +1550,22 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__
     float s[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) s[v] = 0.f;
-    for (int k = 0; k < slices; ++k) {            // slice order: deterministic
+    // slice order: deterministic.  Round 5: eight slices' loads in flight, added IN ORDER (the same sums bit for bit): a 64 -> 64 layer's 128 slices were
+    // 128 dependent round trips of 36 workgroups (30 us per launch, 0.45 ms per step over the small layers)
+    int k = 0;
+    for (; k + 8 <= slices; k += 8) {
+        float p[8][V];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (V == 4) *reinterpret_cast<float4 *>(p[j]) = *reinterpret_cast<const float4 *>(partial + (size_t)(k + j) * n + i);
+            else p[j][0] = partial[(size_t)(k + j) * n + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int v = 0; v < V; ++v) s[v] += p[j][v];
+    }
+    for (; k < slices; ++k) {
         float p[V];
         if (V == 4) *reinterpret_cast<float4 *>(p) = *reinterpret_cast<const float4 *>(partial + (size_t)k * n + i);
         else p[0] = partial[(size_t)k * n + i];
@@ -1562,7 +1577,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__
 }
 
 static void t_wgrad_reduce(hipStream_t s, const float *partial, float *dw, size_t wn, int slices) {
-    if ((wn & 3) == 0 && ((((size_t)partial) | ((size_t)dw)) & 15) == 0)
+    // (small tensors one element per thread: four times the workgroups, the same per-element sums)
+    if ((wn & 3) == 0 && ((((size_t)partial) | ((size_t)dw)) & 15) == 0 && wn >= 256 * 256 * 4)
         hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((wn / 4 + 255) / 256)), dim3(256), 0, s, partial, dw, (int)wn, slices);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, partial, dw, (int)wn, slices);
