@@ -1678,12 +1678,26 @@ static void t_chan_reduce(hipStream_t s, const float *x, const float *dy, const 
         hipLaunchKernelGGL((chan_reduce_kernel<MODE, 1>), dim3((unsigned)C, (unsigned)slices), dim3(256), 0, s, x, dy, out, mean, invstd, gamma, beta, act, N, C, HW, slices, partial);
 }
 
+// sum of a channel's `slices` partial pairs in slice order, eight pairs' loads in flight (the plain loop waited for every pair: a dependent chain of
+// up to 256 round trips in front of every block of the apply kernels); same additions in the same order
+__device__ __forceinline__ void t_sum_partials(const double *__restrict__ p, int slices, double &s, double &ss) {
+    int k = 0;
+    for (; k + 8 <= slices; k += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = p[(k + j) * 2]; b[j] = p[(k + j) * 2 + 1]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s += a[j]; ss += b[j]; }
+    }
+    for (; k < slices; ++k) { s += p[k * 2]; ss += p[k * 2 + 1]; }
+}
+
 __global__ void sums_finish_kernel(const double *__restrict__ partial, int C, int slices, float *__restrict__ out0, float *__restrict__ out1,
                                    const float *__restrict__ invstd) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= C) return;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    t_sum_partials(partial + (size_t)ch * slices * 2, slices, s, ss);
     if (out0) out0[ch] = (float)s;                                     // d beta / d bias
     if (out1) out1[ch] = (float)(invstd ? ss * (double)invstd[ch] : ss);   // d gamma = sum g (x - mean) * invstd
 }
@@ -1700,7 +1714,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     const int p = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const int ch = blockIdx.y % C;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    t_sum_partials(partial + (size_t)ch * slices * 2, slices, s, ss);
     const double dmean = s / count;
     double var = ss / count - dmean * dmean;
     if (var < 0.0) var = 0.0;
@@ -1747,7 +1761,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     const int p = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const int ch = blockIdx.y % C;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < slices; ++k) { s += partial[((size_t)ch * slices + k) * 2]; ss += partial[((size_t)ch * slices + k) * 2 + 1]; }
+    t_sum_partials(partial + (size_t)ch * slices * 2, slices, s, ss);
     const float sum_g = (float)s, sum_gx = (float)ss;
     if (blockIdx.x == 0 && (int)blockIdx.y == ch && threadIdx.x == 0) {
         dbeta[ch] = sum_g;
@@ -1791,11 +1805,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
 }
 
 // AvgPool2d(3, stride 2, padding 1), count_include_pad = True
+// (grid.y = plane, 32-bit pixel arithmetic: the flat 64-bit index cost three 64-bit divisions per element -- round 5)
 __global__ void avgpool_fwd_kernel(const float *__restrict__ x, int H, int W, int Ho, int Wo, size_t total, float *__restrict__ y) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
-    const size_t plane = i / ((size_t)Wo * Ho);
+    const int pp = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (pp >= Ho * Wo) return;
+    const int oy = pp / Wo, ox = pp - oy * Wo;
+    const size_t plane = blockIdx.y;
+    const size_t i = plane * Ho * Wo + pp;
+    (void)total;
     const float *xp = x + plane * H * W;
     float s = 0.f;
     for (int ky = 0; ky < 3; ++ky)
@@ -1807,10 +1824,12 @@ __global__ void avgpool_fwd_kernel(const float *__restrict__ x, int H, int W, in
 }
 
 __global__ void avgpool_bwd_kernel(const float *__restrict__ dy, int H, int W, int Ho, int Wo, size_t total, float *__restrict__ dx) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ix = (int)(i % W), iy = (int)((i / W) % H);
-    const size_t plane = i / ((size_t)W * H);
+    const int pp = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (pp >= H * W) return;
+    const int iy = pp / W, ix = pp - iy * W;
+    const size_t plane = blockIdx.y;
+    const size_t i = plane * H * W + pp;
+    (void)total;
     const float *dp = dy + plane * Ho * Wo;
     float s = 0.f;
     for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy)         // outputs whose window [2oy-1, 2oy+1] holds iy
@@ -2275,7 +2294,8 @@ int pn_avgpool3s2_forward(pn_ctx *ctx, const float *x_dev, float *y_dev, int pla
     if (!x_dev || !y_dev || planes < 1 || H < 1 || W < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_avgpool3s2_forward: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)planes * Ho * Wo;
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, x_dev, H, W, Ho, Wo, total, y_dev);
+    if (planes > 65535) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_avgpool3s2_forward: more than 65535 planes");
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((Ho * Wo + 255) / 256), (unsigned)planes), dim3(256), 0, (hipStream_t)hip_stream, x_dev, H, W, Ho, Wo, total, y_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -2285,7 +2305,8 @@ int pn_avgpool3s2_backward(pn_ctx *ctx, const float *dy_dev, float *dx_dev, int 
     if (!dy_dev || !dx_dev || planes < 1 || H < 1 || W < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_avgpool3s2_backward: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)planes * H * W;
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, dy_dev, H, W, Ho, Wo, total, dx_dev);
+    if (planes > 65535) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_avgpool3s2_backward: more than 65535 planes");
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)planes), dim3(256), 0, (hipStream_t)hip_stream, dy_dev, H, W, Ho, Wo, total, dx_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
