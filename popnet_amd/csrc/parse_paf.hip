@@ -363,8 +363,16 @@ __global__ __launch_bounds__(256) void group_readout_kernel(const float *__restr
     // dependent ~1 us load (measured 25 us per launch).  Stage this frame's 13 KB of scratch in LDS once.
     {
         static_assert(sizeof(ParseWs) % 8 == 0, "staged in 8-byte pieces");
+        // (round 5: every piece of the thread in flight at once -- the plain loop compiled to one load, one s_waitcnt vmcnt(0) per iteration: seven
+        // dependent round trips in front of everything else the block does)
         const uint2 *src = reinterpret_cast<const uint2 *>(&ws[b]);
-        for (int i = tid; i < (int)(sizeof(ParseWs) / 8); i += 256) reinterpret_cast<uint2 *>(s_ws)[i] = src[i];
+        constexpr int NW8 = (int)(sizeof(ParseWs) / 8), NIT = (NW8 + 255) / 256;
+        uint2 stg[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) stg[it] = src[min(tid + 256 * it, NW8 - 1)];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (tid + 256 * it < NW8) reinterpret_cast<uint2 *>(s_ws)[tid + 256 * it] = stg[it];
         // rows beyond n_peaks / n_persons are never written below: the record starts as zeros, so that it is a pure function of its frame
         // (bit-identical wherever in a batch, and in whatever buffer, the frame was processed).  Round 4: zeroed HERE, by the block that owns
         // the record (the barrier below drains these stores -- vmcnt(0) -- before any thread writes a result), instead of by a 1 MB memset
@@ -519,12 +527,26 @@ __global__ __launch_bounds__(256) void group_readout_kernel(const float *__restr
             const float *zm = z_b + (size_t)j * hw;
             float pw_[9], ww_[9];
             int n = 0;
-            for (int yy = min_y; yy <= max_y; ++yy)
-                for (int xx = min_x; xx <= max_x; ++xx) {
-                    float hv = hm[yy * w + xx];
+            // (round 5: the <= 3 x 3 window's eighteen loads are issued before the first is used -- the nested loops with run-time bounds waited for
+            // every cell in turn; same cells, same row-major order, same arithmetic)
+            float hraw[9], zraw[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int o = min(min_y + dy, max_y) * w + min(min_x + dx, max_x);
+                    hraw[dy * 3 + dx] = hm[o];
+                    zraw[dy * 3 + dx] = zm[o];
+                }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (min_y + dy > max_y || min_x + dx > max_x) continue;
+                    float hv = hraw[dy * 3 + dx];
                     if (hv < 0.f) hv = 0.f;
                     const float wv = hv + 0.000000001f;
-                    float dv = zm[yy * w + xx] * cfg.depth_std;
+                    float dv = zraw[dy * 3 + dx] * cfg.depth_std;
                     dv = dv + cfg.depth_mean;
                     pw_[n] = dv * wv;
                     ww_[n] = wv;
