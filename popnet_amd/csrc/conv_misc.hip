@@ -354,7 +354,9 @@ int pn_launch_stem(pn_ctx *ctx, int prec, const float *x, const float *w, const 
 // ---------------------------------------------------------------------------------------------
 // Pooling on NHWC.  One thread = one output pixel x 8 channels (16 B of bf16 / 32 B of f32).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MODE>
+// SPLIT (round 5): the bf16x3 form (value = hi plane + lo plane) as its own instantiation -- with the lo-plane load behind a run-time `if` the
+// compiler waited for every tap's pair before issuing the next (nine dependent round trips: 28 us per launch against 15.7 us for twice the bytes)
+template <typename T, int MODE, bool SPLIT = false>
 __global__ void pool_kernel(const T *__restrict__ in, T *__restrict__ out, int B, int H, int W, int Ho, int Wo,
                             int C8, int in_cs, int out_cs, int out_coff, int in_split, int out_split) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,7 +389,7 @@ __global__ void pool_kernel(const T *__restrict__ in, T *__restrict__ out, int B
             const T *ip = in + ((size_t)(b * H + cy) * W + cx) * in_cs + c8 * 8;
             if (sizeof(T) == 2) {
                 *reinterpret_cast<uint4 *>(v[ky * K + kx]) = *reinterpret_cast<const uint4 *>(ip);
-                if (in_split) *reinterpret_cast<uint4 *>(v2[ky * K + kx]) = *reinterpret_cast<const uint4 *>(ip + in_split);
+                if (SPLIT) *reinterpret_cast<uint4 *>(v2[ky * K + kx]) = *reinterpret_cast<const uint4 *>(ip + in_split);
             } else {
                 reinterpret_cast<uint4 *>(v[ky * K + kx])[0] = reinterpret_cast<const uint4 *>(ip)[0];
                 reinterpret_cast<uint4 *>(v[ky * K + kx])[1] = reinterpret_cast<const uint4 *>(ip)[1];
@@ -398,7 +400,7 @@ __global__ void pool_kernel(const T *__restrict__ in, T *__restrict__ out, int B
         float f[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = (float)v[k][i];
-        if (sizeof(T) == 2 && in_split) {                 // bf16x3: value = hi plane + lo plane
+        if (sizeof(T) == 2 && SPLIT) {                    // bf16x3: value = hi plane + lo plane
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] += (float)v2[k][i];
         }
@@ -431,6 +433,15 @@ static void launch_pool_t(int mode, const void *in, void *out, int B, int H, int
                           int in_cs, int out_cs, int out_coff, int in_split, int out_split, hipStream_t stream) {
     size_t total = (size_t)B * Ho * Wo * (C / 8);
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (sizeof(T) == 2 && in_split) {
+        if (mode == 0)
+            hipLaunchKernelGGL((pool_kernel<T, 0, true>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff, in_split, out_split);
+        else if (mode == 1)
+            hipLaunchKernelGGL((pool_kernel<T, 1, true>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff, in_split, out_split);
+        else
+            hipLaunchKernelGGL((pool_kernel<T, 2, true>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff, in_split, out_split);
+        return;
+    }
     if (mode == 0)
         hipLaunchKernelGGL((pool_kernel<T, 0>), grid, block, 0, stream, (const T *)in, (T *)out, B, H, W, Ho, Wo, C / 8, in_cs, out_cs, out_coff, in_split, out_split);
     else if (mode == 1)
