@@ -50,6 +50,10 @@ __device__ __forceinline__ int t_logical_block() {
     const int xcd = L & 7, idx = L >> 3, qq = nb >> 3, rr = nb & 7;
     return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
 }
+// Sixteen loaded values pinned in registers at this point of the program: every one of their loads has been issued before the first is
+// waited for.  Without it the compiler sinks each load to its single use (legal: the addresses are provably distinct from the stores in
+// between) and waits for it there -- a dependent memory round trip per element.
+#define T_PIN16(a) do { _Pragma("unroll") for (int _k = 0; _k < 16; ++_k) asm volatile("" : "+v"((a)[_k])); } while (0)
 // forward-type grids (tiles, cout blocks): the cout blocks of a tile are neighbours in logical order
 #define T_DECODE_TILE_CB(tile, cb) const int _lg = t_logical_block(), cb = _lg % (int)gridDim.y, tile = _lg / (int)gridDim.y
 // weight-gradient grids (column blocks, cout blocks, slices): a slice's blocks are one contiguous logical range
@@ -131,6 +135,15 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
         }
     }
+    // bias of this lane's sixteen couts, gathered once (round 5: `v += c.bias[co]` inside the store loop compiled to load, s_waitcnt vmcnt(0), add --
+    // sixteen dependent round trips per pixel tile, as did the accumulate form's old values, which the compiler had sunk to their uses)
+    float bv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int co = co0 + 16 * (k >> 2) + 4 * q + (k & 3);
+        bv[k] = c.bias ? c.bias[co < c.Cout ? co : 0] : 0.f;
+    }
+    T_PIN16(bv);
     // epilogue: lane holds couts 16m + 4q + i of pixel 32 wave + 16 n + r; the accumulate form first gathers all old values
     // (32 independent loads in flight), then adds and stores
 #pragma unroll
@@ -149,6 +162,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
                     const int co = co0 + 16 * m + 4 * q + i;
                     old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
                 }
+            T_PIN16(old);                               // all sixteen loads issued, THEN used (see T_PIN16)
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
             for (int i = 0; i < 4; ++i) {
                 const int co = co0 + 16 * m + 4 * q + i;
                 float v = acc[m][n][i];
-                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                v += bv[4 * m + i];
                 if (c.accumulate) v += old[4 * m + i];
                 if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
             }
@@ -295,6 +309,15 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
             }
         }
     }
+    // bias of this lane's sixteen couts, gathered once (round 5: `v += c.bias[co]` inside the store loop compiled to load, s_waitcnt vmcnt(0), add --
+    // sixteen dependent round trips per pixel tile, as did the accumulate form's old values, which the compiler had sunk to their uses)
+    float bv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int co = co0 + 16 * (k >> 2) + 4 * q + (k & 3);
+        bv[k] = c.bias ? c.bias[co < c.Cout ? co : 0] : 0.f;
+    }
+    T_PIN16(bv);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int pok = (int)(opix[n] >= 0);
@@ -308,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
                     const int co = co0 + 16 * m + 4 * q + i;
                     old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
                 }
+            T_PIN16(old);                               // all sixteen loads issued, THEN used (see T_PIN16)
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_kernel(TConv c, TTile g, c
             for (int i = 0; i < 4; ++i) {
                 const int co = co0 + 16 * m + 4 * q + i;
                 float v = acc[m][n][i];
-                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                v += bv[4 * m + i];
                 if (c.accumulate) v += old[4 * m + i];
                 if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
             }
@@ -598,8 +622,12 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
                 *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + (kx * 64 + co) * TX_PITCH + 16 * seg) = co0 + co < c.Cout ? wv[j] : t_u32x4{0u, 0u, 0u, 0u};
             }
             __syncthreads();
-            if (ky < 2) load_w(c0, ky + 1);
-            else if (c0 + 32 < c.Cin) load_w(c0 + 32, 0);
+            {   // ONE call site, always taken (past the last step: the current slice again, unused): two conditional sites merged the loaded
+                // registers through copies that waited for the loads right here
+                const int nc0 = ky == 2 ? c0 + 32 : c0, nky = ky == 2 ? 0 : ky + 1;
+                const bool more = nc0 < c.Cin;
+                load_w(more ? nc0 : c0, more ? nky : ky);
+            }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int toff = (ky * g.HC + kx) * TX_PITCH;
@@ -626,6 +654,15 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
             }
         }
     }
+    // bias of this lane's sixteen couts, gathered once (round 5: `v += c.bias[co]` inside the store loop compiled to load, s_waitcnt vmcnt(0), add --
+    // sixteen dependent round trips per pixel tile, as did the accumulate form's old values, which the compiler had sunk to their uses)
+    float bv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int co = co0 + 16 * (k >> 2) + 4 * q + (k & 3);
+        bv[k] = c.bias ? c.bias[co < c.Cout ? co : 0] : 0.f;
+    }
+    T_PIN16(bv);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int pok = (int)(opix[n] >= 0);
@@ -639,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
                     const int co = co0 + 16 * m + 4 * q + i;
                     old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
                 }
+            T_PIN16(old);                               // all sixteen loads issued, THEN used (see T_PIN16)
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -646,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3_kernel(TConv c, TTile g
             for (int i = 0; i < 4; ++i) {
                 const int co = co0 + 16 * m + 4 * q + i;
                 float v = acc[m][n][i];
-                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                v += bv[4 * m + i];
                 if (c.accumulate) v += old[4 * m + i];
                 if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
             }
@@ -756,8 +794,11 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
                 *reinterpret_cast<t_u32x4 *>((pl ? As_lo : As_hi) + t_swz(kx * 64 + co, seg)) = co0 + co < c.Cout ? wv[j] : t_u32x4{0u, 0u, 0u, 0u};
             }
             __syncthreads();
-            if (ky < 2) load_w(c0, ky + 1);           // the next step's weights, in flight under this step's MFMAs (see tconv3_tile_x3_kernel)
-            else if (c0 + 32 < c.Cin) load_w(c0 + 32, 0);
+            {   // the next step's weights, in flight under this step's MFMAs (see tconv3_tile_x3_kernel)
+                const int nc0 = ky == 2 ? c0 + 32 : c0, nky = ky == 2 ? 0 : ky + 1;
+                const bool more = nc0 < c.Cin;
+                load_w(more ? nc0 : c0, more ? nky : ky);
+            }
 #pragma unroll 1
             for (int kx = 0; kx < 3; ++kx) {          // not unrolled: with three taps' fragments hoisted the kernel spills (124 B / lane)
                 t_bf16x8 bh[4], bl[4];
@@ -786,6 +827,15 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
             }
         }
     }
+    // bias of this lane's sixteen couts, gathered once (round 5: `v += c.bias[co]` inside the store loop compiled to load, s_waitcnt vmcnt(0), add --
+    // sixteen dependent round trips per pixel tile, as did the accumulate form's old values, which the compiler had sunk to their uses)
+    float bv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int co = co0 + 16 * (k >> 2) + 4 * q + (k & 3);
+        bv[k] = c.bias ? c.bias[co < c.Cout ? co : 0] : 0.f;
+    }
+    T_PIN16(bv);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int pok = (int)(opix[n] >= 0);
@@ -799,6 +849,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
                     const int co = co0 + 16 * m + 4 * q + i;
                     old[4 * m + i] = yb[(co * HoWo) & -(int)(co < c.Cout)];
                 }
+            T_PIN16(old);                               // all sixteen loads issued, THEN used (see T_PIN16)
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -806,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void tconv3_tile_x3w_kernel(TConv c, TTile 
             for (int i = 0; i < 4; ++i) {
                 const int co = co0 + 16 * m + 4 * q + i;
                 float v = acc[m][n][i];
-                if (c.bias) v += c.bias[co < c.Cout ? co : 0];
+                v += bv[4 * m + i];
                 if (c.accumulate) v += old[4 * m + i];
                 if (pok && co < c.Cout) yb[(size_t)co * HoWo] = v;
             }
