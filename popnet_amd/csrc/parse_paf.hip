@@ -110,11 +110,14 @@ __global__ __launch_bounds__(256) void peaks_refine_kernel(const float *__restri
     __shared__ unsigned short s_wlist[4][MAXP];      // per-wave ordered peak lists (cell index)
     __shared__ int s_px[MAXP], s_py[MAXP];
     __shared__ float s_h[4][5 * 40];                 // per wave: horizontal pass of the patch being refined
+    __shared__ __attribute__((aligned(16))) float s_tab[8][4];   // the cubic coefficients: indexed by a per-lane phase in the refinement loops -- from the kernel
+                                                     // argument that index is a vector-memory load per loop iteration (25 dependent ones per peak, round 5)
     const int joint = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hw = h * w;
     const float *src = heat + ((size_t)b * heat_c + joint) * hw;
     for (int i = tid; i < hw; i += 256) map[i] = src[i];
+    if (tid < 32) s_tab[tid >> 2][tid & 3] = tab.c[tid >> 2][tid & 3];
     __syncthreads();
 
     // peak <=> v == max over the 4-connected cross (scipy 'reflect': an out-of-image neighbour is
@@ -176,29 +179,41 @@ __global__ __launch_bounds__(256) void peaks_refine_kernel(const float *__restri
         const float inv_uw = 1.0f / (float)uw;
         const float *patch = map + y_min * w + x_min;
         float *hb = s_h[wave];
-        for (int i = lane; i < ph * uw; i += 64) {
-            const int r = (int)(((float)i + 0.5f) * inv_uw), ux = i - r * uw;
-            int sx0, phx;
-            up8_src(ux, sx0, phx);
-            const float *row = patch + r * w;
-            float hv = row[min(max(sx0, 0), pw - 1)] * tab.c[phx][0];
-            hv = hv + row[min(max(sx0 + 1, 0), pw - 1)] * tab.c[phx][1];
-            hv = hv + row[min(max(sx0 + 2, 0), pw - 1)] * tab.c[phx][2];
-            hv = hv + row[min(max(sx0 + 3, 0), pw - 1)] * tab.c[phx][3];
-            hb[r * 40 + ux] = hv;
+        // (fixed trip counts -- <= 5 x 40 and <= 40 x 40 values -- so that the LDS reads of several iterations are in flight; same values in the
+        // same ascending order per lane)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = lane + 64 * it;
+            if (i < ph * uw) {
+                const int r = (int)(((float)i + 0.5f) * inv_uw), ux = i - r * uw;
+                int sx0, phx;
+                up8_src(ux, sx0, phx);
+                const float *row = patch + r * w;
+                const float4 cf = *reinterpret_cast<const float4 *>(s_tab[phx]);
+                float hv = row[min(max(sx0, 0), pw - 1)] * cf.x;
+                hv = hv + row[min(max(sx0 + 1, 0), pw - 1)] * cf.y;
+                hv = hv + row[min(max(sx0 + 2, 0), pw - 1)] * cf.z;
+                hv = hv + row[min(max(sx0 + 3, 0), pw - 1)] * cf.w;
+                hb[r * 40 + ux] = hv;
+            }
         }
         WAVE_LDS_SYNC();
         float best = -INFINITY;
         int best_i = 0x7fffffff;
-        for (int i = lane; i < un; i += 64) {
-            const int uy = (int)(((float)i + 0.5f) * inv_uw), ux = i - uy * uw;
-            int sy0, phy;
-            up8_src(uy, sy0, phy);
-            float v = hb[min(max(sy0, 0), ph - 1) * 40 + ux] * tab.c[phy][0];
-            v = v + hb[min(max(sy0 + 1, 0), ph - 1) * 40 + ux] * tab.c[phy][1];
-            v = v + hb[min(max(sy0 + 2, 0), ph - 1) * 40 + ux] * tab.c[phy][2];
-            v = v + hb[min(max(sy0 + 3, 0), ph - 1) * 40 + ux] * tab.c[phy][3];
-            if (v > best || best_i == 0x7fffffff) { best = v; best_i = i; }   // i ascending: first max kept
+#pragma unroll 5
+        for (int it = 0; it < 25; ++it) {
+            const int i = lane + 64 * it;
+            if (i < un) {
+                const int uy = (int)(((float)i + 0.5f) * inv_uw), ux = i - uy * uw;
+                int sy0, phy;
+                up8_src(uy, sy0, phy);
+                const float4 cf = *reinterpret_cast<const float4 *>(s_tab[phy]);
+                float v = hb[min(max(sy0, 0), ph - 1) * 40 + ux] * cf.x;
+                v = v + hb[min(max(sy0 + 1, 0), ph - 1) * 40 + ux] * cf.y;
+                v = v + hb[min(max(sy0 + 2, 0), ph - 1) * 40 + ux] * cf.z;
+                v = v + hb[min(max(sy0 + 3, 0), ph - 1) * 40 + ux] * cf.w;
+                if (v > best || best_i == 0x7fffffff) { best = v; best_i = i; }   // i ascending: first max kept
+            }
         }
         for (int off = 32; off > 0; off >>= 1) {
             float ov = __shfl_xor(best, off);
@@ -234,6 +249,7 @@ __global__ __launch_bounds__(256) void limb_match_kernel(const float *__restrict
     __shared__ unsigned char s_cand_i[MAXP * MAXP], s_cand_j[MAXP * MAXP];
     __shared__ unsigned short s_order[MAXP * MAXP];
     __shared__ int s_ncand;
+    __shared__ CubicTab s_tab;                   // (per-lane phases index it: LDS reads instead of vector-memory loads from the kernel argument)
     const int limb = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x;
     ParseWs &W = ws[b];
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(256) void limb_match_kernel(const float *__restrict
         pmap[1][i] = px_map[hw + i];
     }
     if (tid == 0) s_ncand = 0;
+    if (tid < 32) s_tab.c[tid >> 2][tid & 3] = tab.c[tid >> 2][tid & 3];
     __syncthreads();
 
     const int npairs = ns * nd;
@@ -269,8 +286,8 @@ __global__ __launch_bounds__(256) void limb_match_kernel(const float *__restrict
             const double stepx = (ex - sx) / 9.0, stepy = (ey - sy) / 9.0;
             const int qx = linspace_round(sx, ex, stepx, pt, 10);
             const int qy = linspace_round(sy, ey, stepy, pt, 10);
-            const float vx = bicubic8(pmap[0], w, h, w, qy, qx, tab);
-            const float vy = bicubic8(pmap[1], w, h, w, qy, qx, tab);
+            const float vx = bicubic8(pmap[0], w, h, w, qy, qx, s_tab);
+            const float vy = bicubic8(pmap[1], w, h, w, qy, qx, s_tab);
             s_pts[lp][pt] = (double)vx * dxn + (double)vy * dyn;
         }
         __syncthreads();
