@@ -343,12 +343,17 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
             bias[4 * ct + 0] = b4[0]; bias[4 * ct + 1] = b4[1]; bias[4 * ct + 2] = b4[2]; bias[4 * ct + 3] = b4[3];
         }
         const int act = P.act;
+        // bf16x3 (round 5): the convolution's value is parked as its two planes hi = bf16(v), lo = bf16(v - hi) -- what the unfused launch stores --
+        // the lo tile PARK bytes behind the hi tile; the window sums add (float)hi + (float)lo per tap like pool_kernel<.., SPLIT> and the pooled
+        // value leaves as two planes `tail_split` channels apart
+        constexpr int PARK = 4 * PT * 1024;
+        const int tsplit = P.tail_split;
         __syncthreads();                                 // every wave is done reading the halo image: its space becomes the parked tile
         auto park = [&](auto actc) {
             constexpr int ACT = decltype(actc)::value;
 #pragma clang loop unroll(full)
             for (int pt = 0; pt < PT; ++pt) {
-                T ov[LC];
+                T ov[LC], ol[LC];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -357,8 +362,10 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
                         if (ACT == PN_ACT_RELU) v = v > 0.f ? v : 0.f;
                         else if (ACT == PN_ACT_LEAKY) v = v > 0.f ? v : v * 0.1f;
                         ov[4 * ct + i] = (T)v;
+                        ol[4 * ct + i] = (T)(v - (float)ov[4 * ct + i]);
                     }
                 *reinterpret_cast<u32x4 *>(smem + ((wc * PT + pt) * 64 + lane) * 16) = *reinterpret_cast<u32x4 *>(ov);
+                if (tsplit) *reinterpret_cast<u32x4 *>(smem + PARK + ((wc * PT + pt) * 64 + lane) * 16) = *reinterpret_cast<u32x4 *>(ol);
             }
         };
         if (act == PN_ACT_RELU) park(std::integral_constant<int, PN_ACT_RELU>{});
@@ -383,14 +390,28 @@ __device__ __forceinline__ void conv3_body(const ConvProblem &P) {
                     const bool ok = (unsigned)(oy0 + ry) < (unsigned)P.Ho && (unsigned)(ox0 + rx) < (unsigned)Wo;
                     const int slot = ry * 15 + rx;
                     T tv[8];
-                    *reinterpret_cast<u32x4 *>(tv) = *reinterpret_cast<const u32x4 *>(smem + ((wq * PT + (slot >> 4)) * 64 + qq * 16 + (slot & 15)) * 16);
+                    const int toff = ((wq * PT + (slot >> 4)) * 64 + qq * 16 + (slot & 15)) * 16;
+                    *reinterpret_cast<u32x4 *>(tv) = *reinterpret_cast<const u32x4 *>(smem + toff);
+                    if (tsplit) {
+                        T tl[8];
+                        *reinterpret_cast<u32x4 *>(tl) = *reinterpret_cast<const u32x4 *>(smem + PARK + toff);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) a8[k] += ok ? (float)tv[k] : 0.f;
+                        for (int k = 0; k < 8; ++k) { float f = (float)tv[k]; f += (float)tl[k]; a8[k] += ok ? f : 0.f; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a8[k] += ok ? (float)tv[k] : 0.f;
+                    }
                 }
-            T o8[8];
+            T o8[8], l8[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o8[k] = (T)(a8[k] / 9.0f);
-            *reinterpret_cast<PN_GLOBAL u32x4 *>(pout + ((size_t)(b * Hp + py) * Wp + px) * (size_t)P.tail_out_cs + g8 * 8) = *reinterpret_cast<u32x4 *>(o8);
+            for (int k = 0; k < 8; ++k) {
+                const float rr = a8[k] / 9.0f;
+                o8[k] = (T)rr;
+                l8[k] = (T)(rr - (float)o8[k]);
+            }
+            PN_GLOBAL T *op = pout + ((size_t)(b * Hp + py) * Wp + px) * (size_t)P.tail_out_cs + g8 * 8;
+            *reinterpret_cast<PN_GLOBAL u32x4 *>(op) = *reinterpret_cast<u32x4 *>(o8);
+            if (tsplit) *reinterpret_cast<PN_GLOBAL u32x4 *>(op + tsplit) = *reinterpret_cast<u32x4 *>(l8);
         }
         PN_STAMP_AT(12);
         return;

@@ -708,9 +708,9 @@ void fuse_1x1_tails(pn_net *n, std::vector<std::vector<int>> &levels) {
 // convolution is per pixel, so a block can compute exactly the 7 x 15 patch that 3 x 7 pooled pixels need and sum the windows
 // from LDS (conv3_kernel.h, TAIL == 2).  The pool launch and the full-resolution map (25.7 MB written and read back at B = 32)
 // disappear; blocks recompute one shared row and column (25 % more matrix work on a bandwidth-bound layer).  Same values, same
-// summation order as the two launches: bit-identical (POPNET_NO_POOLFUSE=1 keeps them).  bf16 only.
+// summation order as the two launches: bit-identical (POPNET_NO_POOLFUSE=1 keeps them).  bf16 and (round 5) bf16x3: the parked tile as two planes.
 void fuse_pool_tails(pn_net *n, std::vector<std::vector<int>> &levels) {
-    if (n->prec != PN_PREC_BF16 || n->x3 || getenv("POPNET_NO_POOLFUSE") || getenv("POPNET_NO_CONV3")) return;
+    if (n->prec != PN_PREC_BF16 || getenv("POPNET_NO_POOLFUSE") || getenv("POPNET_NO_CONV3")) return;       // (bf16x3 since round 5: two parked planes)
     for (size_t li = 0; li + 1 < levels.size(); ++li) {
         if (levels[li].size() != 1 || levels[li][0] < 0) continue;
         const std::vector<int> &pl = levels[li + 1];
@@ -976,6 +976,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
                 P.tiles_per_img = ((pb.H + 2) / 3) * P.tiles_x;
                 P.nblocks = B * P.tiles_per_img * P.cout_blocks;
                 P.tail_out = pb.p; P.tail_out_cs = pb.C; P.tail_out_coff = cs.pool_out_coff;
+                P.tail_split = n->x3 ? pb.plane : 0;
                 P.out = nullptr;
                 pool_tail = true;
             }
@@ -1007,6 +1008,7 @@ int refresh_problems(pn_net *n, int B, hipStream_t stream) {
                 st.launch.lds_bytes = std::max(st.launch.lds_bytes, pn_conv3_lds_bytes(cs.ks, cs.wp, cs.nbuf, cs.rpg));
             }
             if (st.launch.tail == 1) st.launch.lds_bytes = std::max<size_t>(st.launch.lds_bytes, 4 * 7 * 1024 + 1024);   // the tail's fragment image
+            if (st.launch.tail == 2 && n->x3) st.launch.lds_bytes = std::max<size_t>(st.launch.lds_bytes, 2 * 4 * 7 * 1024);   // fused pool, bf16x3: hi and lo tiles parked
         }
         if (c0.kern == 4) st.launch.lds_bytes = 0;                        // conv4_launch knows its own size
         st.launch.probs_dev = st.dev_probs;

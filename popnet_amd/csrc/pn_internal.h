@@ -115,6 +115,7 @@ struct ConvProblem {
     void *tail_out;        // NHWC (T) or nullptr
     float *tail_nchw;      // NCHW f32 or nullptr
     int tail_cout, tail_act, tail_out_cs, tail_out_coff;
+    int tail_split;        // fused average pool in a bf16x3 net: plane distance (channels) of the pooled [hi | lo] output, 0 = plain bf16
 };
 
 // Tile configuration ids (see conv_mfma.hip).
