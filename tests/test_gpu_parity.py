@@ -735,6 +735,30 @@ def test_paf_to_pose_cpp_vs_reference_function_golden(gpu, golden, seed, P):
     assert (len(humans) > 0) == (P > 0)
 
 
+def test_nms_peaks_has_no_capacity_and_keeps_the_reference_order(gpu):
+    """pn_nms_peaks (the NMS behind paf_to_pose_cpp) against the oracle's restatement of paf_to_pose.py:75-153 on maps the fixed-size parse
+    records could not hold: a plateau-riddled map with hundreds of peaks, an empty map, a single-cell plateau pair at the border, 21 maps."""
+    from types import SimpleNamespace
+    from oracle import parse_paf as O
+    from popnet_amd.utils import paf_to_pose as P2P
+    rng = np.random.default_rng(77)
+    h, w, nk = 28, 28, 21
+    heat = rng.uniform(0.0, 0.09, (h, w, nk)).astype(np.float32)
+    heat[:, :, 0] = (rng.integers(0, 3, (h, w)) * 0.25 + 0.2).astype(np.float32)         # three-level plateaus: > 100 peaks
+    heat[:, :, 1] = 0.0                                                                   # nothing above the threshold
+    heat[0, 0, 2] = heat[0, 1, 2] = 0.7                                                   # two-cell plateau in the corner
+    heat[h - 1, w - 1, 3] = 0.9
+    for j in range(4, nk):
+        for _ in range(int(rng.integers(0, 6))):
+            heat[rng.integers(0, h), rng.integers(0, w), j] = rng.uniform(0.2, 1.0)
+    cfg = SimpleNamespace(MODEL=SimpleNamespace(DOWNSAMPLE=8, NUM_KEYPOINTS=nk), TEST=SimpleNamespace(THRESH_HEATMAP=0.1))
+    got = P2P.NMS(heat.copy(), upsampFactor=8, config=cfg)
+    ref = O.nms(heat.copy(), num_keypoints=nk)
+    assert len(got) == nk and len(got[0]) > 100 and len(got[1]) == 0
+    for j in range(nk):
+        assert got[j].shape == ref[j].shape and np.array_equal(got[j], ref[j]), j
+
+
 def test_pafprocess_rejects_out_of_range_peaks(gpu):
     from popnet_amd import pafprocess
     pk = np.array([[[500, 3, 0.9, 0, 1]]], np.float32)        # x outside the 216-wide map: the reference reads out of bounds

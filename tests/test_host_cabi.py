@@ -127,3 +127,33 @@ def test_shard_indices_cover_all_frames_once():
     for n, w in ((4484, 8), (10, 3), (7, 8), (32, 1)):
         seen = sorted(i for r in range(w) for i in shard_indices(n, r, w))
         assert seen == list(range(n))
+
+
+def test_bench_line_carries_the_parity_mode_inside_config_and_roofline():
+    """bench.surface_in_parsed: the driver keeps `config` / `roofline` verbatim and only NAMES other keys, so the
+    tolerance-meeting mode's throughput and fidelity, the H2D-inclusive rate and the headline mode's own tolerance verdict must live inside
+    those two objects -- nested once and as flat scalars."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fid = {"frames": 96, "same_person_count": 95, "same_assignment": 95, "d3_m_max": 5.5e-5}
+    out = {"config": {"workload": "w"}, "roofline": {"frac": 0.38, "conv_stack": {"frac": 0.31}},
+           "h2d_inclusive": {"value": 63000.0, "fraction_of_value": 0.95, "host_link": {"GBps": 55.6}},
+           "fidelity": {"meets_north_star_tolerance": False, "same_assignment": "29/96", "d3_m_max": 0.03},
+           "parity_mode": {"dtype": "bf16x3", "value": 26000.0, "ms_per_step": 1.23, "h2d_inclusive": {"value": 25500.0},
+                           "roofline": {"frac": 0.45, "algorithmic_tflops": 373.0, "peak": 2500.0, "conv_stack_physical_frac": 0.37},
+                           "fidelity": {"threshold_calibrated_weights": fid, "separated_weights": fid}},
+           "train_step": {"ms_per_step": 20.7, "bf16x3": {"ms_per_step": 9.7}}, "yolo": {"value": 97000.0, "conv_stack": {"frac": 0.26}},
+           "postproc": {"us_per_step": 50.0}}
+    bench.surface_in_parsed(out)
+    cfg, rf = out["config"], out["roofline"]
+    for block in (cfg["parity_mode"], rf["parity_mode"]):
+        assert block["dtype"] == "bf16x3" and block["value"] == 26000.0 and block["h2d_inclusive"] == 25500.0
+        assert block["same_assignment"] == "95/96" and block["meets_north_star_tolerance"] is True
+        assert abs(block["frac_algorithmic"] - 373.0 / 2500.0) < 1e-4 and block["frac_physical"] == 0.45
+    assert cfg["parity_mode_value"] == 26000.0 and cfg["parity_mode_meets_north_star_tolerance"] is True
+    assert cfg["h2d_inclusive_value"] == 63000.0 and cfg["value_meets_north_star_tolerance"] is False
+    assert cfg["train_step_ms_fp32"] == 20.7 and cfg["train_step_ms_bf16x3"] == 9.7 and cfg["yolo_value"] == 97000.0
+    assert rf["conv_stack_frac"] == 0.31 and rf["postproc_us_per_step"] == 50.0
+    bare = {"config": {}, "roofline": {}}                      # a line without the secondary legs (N > 1, --no-extras) stays valid
+    bench.surface_in_parsed(bare)
+    assert "parity_mode" not in bare["config"]
