@@ -147,6 +147,8 @@ def NMS(heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=F
     dev = torch.device("cuda", torch.cuda.current_device())
     hm = torch.as_tensor(np.ascontiguousarray(heatmaps) if isinstance(heatmaps, np.ndarray) else heatmaps)
     nk = int(config.MODEL.NUM_KEYPOINTS)
+    if hm.dim() != 3 or hm.shape[2] < nk:
+        raise _lib.PopnetError("NMS: heatmaps must be [h, w, >= %d] (HWC), got %s" % (nk, tuple(hm.shape)))
     hm = hm.to(dev, torch.float32).permute(2, 0, 1)[:nk].contiguous()
     _, h, w = hm.shape
     cnt = torch.zeros((nk,), device=dev, dtype=torch.int32)
