@@ -25,6 +25,10 @@
 //     piece issued one phase earlier: 530 cycles per 320-cycle phase against 355 per 256 in conv2 (scripts/bblab.hip);
 //   * one barrier per TWO k-steps (a bare s_barrier for the compute waves: their fragment reads stay in flight across it):
 //     20 barriers per tile instead of 38; 160 KB of LDS, one workgroup per CU.
+//   * round 5: the tiles are handed out by TICKET (one atomic per tile, fetched a tile ahead by an image-loader wave and published through four spare
+//     bytes of the intermediate image), not by blockIdx.x + k * gridDim.x: a persistent workgroup can only start on a CU that holds no other wave, so among
+//     the other in-flight batches' launches some workgroups start late -- with the static schedule the launch ended when the LATEST starter had walked its
+//     seven tiles; now the early ones take its share.  Which workgroup computes which tile changes, nothing else.
 // Weight pack (net.hip): [36 k-steps = (conv, half, tap)][4 cout tiles][64 lanes][8 bf16], rows permuted with
 // pn_conv_row_channel(tile, row, 4) so that a lane's 16 accumulators are 16 consecutive channels.
 #pragma once
@@ -64,6 +68,13 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
     const int c = lane & 15, q = lane >> 4;
     const int W = P.W, H = P.H;
 
+    // ticket slots: pixel column 31 of row 0 of the intermediate image's first quarter plane is never written (MC <= 30) nor read (x + kx <= 29)
+    volatile int *s_tile = reinterpret_cast<volatile int *>(smem + BB_OFF_MID + 31 * 32);
+    const bool dyn = P.tickets != nullptr;
+    // tile k + 1 of this workgroup, as every wave sees it at the start of tile k (static schedule: t + gridDim.x)
+    auto next_tile = [&](int t, int k) -> int { return dyn ? __builtin_amdgcn_readfirstlane(s_tile[(k + 1) & 3]) : t + (int)gridDim.x; };
+    // (the compute and weight-loader waves need it at the END of tile k only: they issue the LDS read at the start and look at it there)
+    auto next_tile_raw = [&](int t, int k) -> int { return dyn ? s_tile[(k + 1) & 3] : t + (int)gridDim.x; };
     auto tile_geom = [&](int t, int &b, int &oy0, int &ox0, int &R, int &Wc) {
         b = t / P.tiles_per_img;
         const int rem = t - b * P.tiles_per_img;
@@ -92,7 +103,8 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             dma_a(0); dma_a(1); dma_a(2); dma_a(3);             // phases 0 and 1
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             asm volatile("s_barrier" ::: "memory");              // (the compute waves have read k-step 0's fragments)
-            for (; t < P.ntiles; t += gridDim.x) {
+            for (int k = 0; t < P.ntiles; ++k) {
+                const int tnx = next_tile_raw(t, k);
 #pragma clang loop unroll(full)
                 for (int p = 0; p < 18; ++p) {                   // phase p = k-steps 2p, 2p + 1 of the tile's 36
 #ifndef BB_FAKE_NODMA_A
@@ -105,6 +117,7 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                     if (p == 8) asm volatile("s_barrier" ::: "memory");          // the compute waves publish the intermediate image
                 }
                 asm volatile("s_barrier" ::: "memory");                             // end of tile
+                t = __builtin_amdgcn_readfirstlane(tnx);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
@@ -122,13 +135,29 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             pn_glds16_s<0>((const char *)P.in + frame_b, off, (unsigned)__builtin_amdgcn_readfirstlane(buf * BB_IN + qu * BB_INQ + row * 1024));
         };
         const int n0 = (lw - 2) * 24;
+        const bool ticketer = dyn && lw == 2 && lane == 0;      // this lane fetches the tickets: tile 1 now, tile k + 2 during tile k
+        int ticket = 0;
+        // (hybrids -- the first tiles of a workgroup by position, only its last 1, 2 or 3 by ticket -- measured no better than the static schedule:
+        //  profiles/r05_notes.txt)
+        auto claim = [&]() -> int {
+#ifdef BB_TICKET_FAKE             // timing experiment: the ticket protocol without the atomics (the static sequence through LDS)
+            return (ticket ? ticket : t) + (int)gridDim.x;
+#else
+            return (int)gridDim.x + atomicAdd(P.tickets, 1);
+#endif
+        };
+        if (ticketer) ticket = claim();
 #pragma unroll
         for (int j = 0; j < 24; ++j) dma_in(t, 0, n0 + j);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ticketer) s_tile[1] = ticket;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         int cur = 0;
-        for (; t < P.ntiles; t += gridDim.x) {
-            const int tn = t + (int)gridDim.x < P.ntiles ? t + (int)gridDim.x : t;      // past the last tile: a harmless refetch into the idle image
+        for (int k = 0; t < P.ntiles; ++k) {
+            const int tnx = next_tile(t, k);
+            const int tn = tnx < P.ntiles ? tnx : t;             // past the last tile: a harmless refetch into the idle image
+            if (ticketer) ticket = claim();
 #pragma clang loop unroll(full)
             for (int p = 0; p < 18; ++p) {
 #ifndef BB_FAKE_NODMA_IN
@@ -137,8 +166,11 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 asm volatile("s_barrier" ::: "memory");
                 if (p == 8) asm volatile("s_barrier" ::: "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");             // end of tile: the next image is complete
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // end of tile: the next image is complete (and the ticket is back)
+            if (ticketer) s_tile[(k + 2) & 3] = ticket;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             cur ^= 1;
+            t = tnx;
         }
         return;
     }
@@ -158,7 +190,8 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int cur = 0;
     PN_STAMP_AT(0);
-    for (int it = 0; t < P.ntiles; t += gridDim.x, ++it) {
+    for (int it = 0; t < P.ntiles; ++it) {
+        const int tnx = next_tile_raw(t, it);
         int b, oy0, ox0, R, Wc;
         tile_geom(t, b, oy0, ox0, R, Wc);
         if (it == 2) PN_STAMP_AT(1);                     // third tile: steady state
@@ -305,6 +338,13 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the loader may now refill this image's buffer
         if (it == 2) PN_STAMP_AT(5);
         cur ^= 1;
+        t = __builtin_amdgcn_readfirstlane(tnx);
+    }
+    if (dyn && tid == 0) {                               // the last workgroup to finish leaves both counters at zero for the next launch (graph replay)
+        if (atomicAdd(P.tickets + 1, 1) == (int)gridDim.x - 1) {
+            __hip_atomic_store(P.tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.tickets + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     PN_STAMP_AT(12);
 #undef BB_OFF1

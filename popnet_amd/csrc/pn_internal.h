@@ -168,6 +168,9 @@ struct BBProblem {
     unsigned in_zero_off;  // byte offset from `in` to >= 16 zero bytes
     // bb64x3_kernel (bf16x3 nets): plane distance in channels of the three-plane [hi | lo | hi] input / output tensors; wpack = 72 x 4 KB
     int in_split, out_split;
+    // bb64_kernel (round 5): two zero-initialised ints in device memory -- [0] the next tile ticket, [1] the number of workgroups that have finished (the last
+    // one resets both, so a replayed graph finds zeros again).  nullptr = the static schedule (tile = blockIdx.x + k * gridDim.x)
+    int *tickets;
 };
 int pn_launch_bb64(pn_ctx *ctx, const BBProblem &P, hipStream_t stream);       // bb64_inst.hip
 int pn_launch_bb64x3(pn_ctx *ctx, const BBProblem &P, hipStream_t stream);     // bb64x3_inst.hip (6-row tiles: tiles_per_img = ceil(H / 6) * tiles_x)

@@ -258,7 +258,7 @@ def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, mo
         assert torch.equal(got4_y, ref_y)
 
 
-@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0", "POPNET_NO_BBLOCK=1", "POPNET_NO_TAILFUSE=1", "POPNET_NO_MIX=1", "POPNET_NO_POOLFUSE=1", "POPNET_GENERIC_C64=0", "POPNET_NO_STEMPOOL=1", "POPNET_NO_EMBED3=1"])
+@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0", "POPNET_NO_BBLOCK=1", "POPNET_NO_TAILFUSE=1", "POPNET_NO_MIX=1", "POPNET_NO_POOLFUSE=1", "POPNET_GENERIC_C64=0", "POPNET_NO_STEMPOOL=1", "POPNET_NO_EMBED3=1", "POPNET_BB64_STATIC=1"])
 def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, monkeypatch):
     """The experiment switches of profiles/README.md (224-pixel wave tiles, double-buffered halo images, 8-row tiles on
     14-column maps; conv4_kernel on every / no level; the two layer1 BasicBlocks as two launches each instead of the fused
@@ -284,6 +284,20 @@ def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, mo
     for a, b, name in zip(got, ref, ("paf", "heat", "z")):
         assert torch.isfinite(a).all() and torch.equal(a, b), (switch, name)
     assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y), switch
+
+
+def test_bb64_tile_tickets_are_left_at_zero_for_the_next_launch(gpu, golden):
+    """bb64_kernel hands its tiles out by ticket (round 5); the last workgroup to finish resets the two counters, so the same net --
+    eager or as a replayed graph -- gives the same maps launch after launch (a stale counter would skip every tile past the first
+    per workgroup: 32 frames of 224x224 are 1792 tiles for 256 workgroups)."""
+    x = torch.from_numpy(np.random.default_rng(61).normal(0, 1, (32, 1, 224, 224)).astype(np.float32)).to(gpu)
+    net = _rtpose(golden, "bf16")
+    first = [t.clone() for t in net(x)[0]]
+    for _ in range(4):
+        again = [t.clone() for t in net(x)[0]]
+        for a, b, name in zip(again, first, ("paf", "heat", "z")):
+            assert torch.equal(a, b), name
+    assert all(torch.isfinite(t).all() for t in first)
 
 
 @pytest.mark.parametrize("hw,B", [((224, 224), 3), ((200, 232), 2), ((256, 192), 2)])
