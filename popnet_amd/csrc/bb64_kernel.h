@@ -25,7 +25,7 @@
 //     piece issued one phase earlier: 530 cycles per 320-cycle phase against 355 per 256 in conv2 (scripts/bblab.hip);
 //   * one barrier per TWO k-steps (a bare s_barrier for the compute waves: their fragment reads stay in flight across it):
 //     20 barriers per tile instead of 38; 160 KB of LDS, one workgroup per CU.
-//   * round 5: the tiles are handed out by TICKET (one atomic per tile, fetched a tile ahead by an image-loader wave and published through four spare
+//   * round 5: the tiles are handed out by TICKET (one atomic per tile, fetched a tile ahead by an image-loader wave and published through sixteen spare
 //     bytes of the intermediate image), not by blockIdx.x + k * gridDim.x: a persistent workgroup can only start on a CU that holds no other wave, so among
 //     the other in-flight batches' launches some workgroups start late -- with the static schedule the launch ended when the LATEST starter had walked its
 //     seven tiles; now the early ones take its share.  Which workgroup computes which tile changes, nothing else.
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             pn_glds16_s<0>((const char *)P.in + frame_b, off, (unsigned)__builtin_amdgcn_readfirstlane(buf * BB_IN + qu * BB_INQ + row * 1024));
         };
         const int n0 = (lw - 2) * 24;
-        const bool ticketer = dyn && lw == 2 && lane == 0;      // this lane fetches the tickets: tile 1 now, tile k + 2 during tile k
+        const bool ticketer = dyn && lw == 2 && lane == 0;      // this lane fetches the tickets: tile k + 2 during tile k
         int ticket = 0;
         // (hybrids -- the first tiles of a workgroup by position, only its last 1, 2 or 3 by ticket -- measured no better than the static schedule:
         //  profiles/r05_notes.txt)
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
 #ifdef BB_TICKET_FAKE             // timing experiment: the ticket protocol without the atomics (the static sequence through LDS)
             return (ticket ? ticket : t) + (int)gridDim.x;
 #else
-            return (int)gridDim.x + atomicAdd(P.tickets, 1);
+            return 2 * (int)gridDim.x + atomicAdd(P.tickets, 1);
 #endif
         };
-        if (ticketer) ticket = claim();
+        if (ticketer) ticket = t + (int)gridDim.x;             // the first two tiles of a workgroup by position: the prologue waits for no atomic
 #pragma unroll
         for (int j = 0; j < 24; ++j) dma_in(t, 0, n0 + j);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -157,7 +157,14 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         for (int k = 0; t < P.ntiles; ++k) {
             const int tnx = next_tile(t, k);
             const int tn = tnx < P.ntiles ? tnx : t;             // past the last tile: a harmless refetch into the idle image
-            if (ticketer) ticket = claim();
+            // a workgroup on its LAST tile has no use for another ticket: it signs off instead (looked at after the end-of-tile wait, ten microseconds
+            // later: the kernel's end does not wait for an atomic's round trip).  The workgroup that signs off last knows every claim has been made and
+            // leaves both counters at zero for the next launch (graph replay).
+            int signed_off = -1;
+            if (ticketer) {
+                if (tnx < P.ntiles) ticket = claim();
+                else signed_off = atomicAdd(P.tickets + 1, 1);
+            }
 #pragma clang loop unroll(full)
             for (int p = 0; p < 18; ++p) {
 #ifndef BB_FAKE_NODMA_IN
@@ -167,7 +174,13 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 if (p == 8) asm volatile("s_barrier" ::: "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // end of tile: the next image is complete (and the ticket is back)
-            if (ticketer) s_tile[(k + 2) & 3] = ticket;
+            if (ticketer) {
+                s_tile[(k + 2) & 3] = ticket;
+                if (signed_off == (int)gridDim.x - 1) {
+                    __hip_atomic_store(P.tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(P.tickets + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             cur ^= 1;
             t = tnx;
@@ -339,12 +352,6 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         if (it == 2) PN_STAMP_AT(5);
         cur ^= 1;
         t = __builtin_amdgcn_readfirstlane(tnx);
-    }
-    if (dyn && tid == 0) {                               // the last workgroup to finish leaves both counters at zero for the next launch (graph replay)
-        if (atomicAdd(P.tickets + 1, 1) == (int)gridDim.x - 1) {
-            __hip_atomic_store(P.tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(P.tickets + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     PN_STAMP_AT(12);
 #undef BB_OFF1

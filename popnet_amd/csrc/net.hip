@@ -1175,6 +1175,7 @@ int pn_net_finalize(pn_net *n, int precision, int max_batch, int in_h, int in_w)
         if (st.type == Step::CONV)
             if (int r = dev_alloc(n, (void **)&st.dev_probs, st.conv_ids.size() * sizeof(ConvProblem), true)) return r;
     n->tensors.clear();
+    PN_HIP_CHECK(ctx, hipDeviceSynchronize());      // the zero fills above ran on the null stream: a forward on a non-blocking stream must not overtake them
     n->finalized = true;
     return PN_OK;
 }
