@@ -15,7 +15,7 @@
 //     of x), and y leaves with 16-B stores;
 //   * the input image is double-buffered: the next tile's image is fetched during this tile's conv1, the stores of
 //     this tile drain under the next tile's conv1 -- no lockstep memory phases;
-//   * 8 waves with FIXED ROLES: waves 0-3 compute (each 64 couts x 5 / 4 pixel tiles: 20 / 16 MFMAs per k-step, B
+//   * 8 waves (HV = 1) with FIXED ROLES: waves 0-3 compute (each 64 couts x 5 / 4 pixel tiles: 20 / 16 MFMAs per k-step, B
 //     fragments from the images, A fragments from a 6-slot LDS ring), waves 4-7 only issue LDS-DMA and count their own
 //     vmcnt -- a compute wave's instruction stream is MFMA + ds_read only (conv4_kernel's ablations: DMA issue and its
 //     waits cost a lone wave 80 of 717 cycles per k-step).  Round 3: the loaders are split by STREAM -- waves 4, 5 fetch
@@ -58,9 +58,16 @@ __device__ __forceinline__ unsigned bb_relu_pk(unsigned w) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), i16x2{0, 0}));
 }
 
-__global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
+// HV = 1 (default): four compute waves of 64 couts.  HV = 2 (round 5, POPNET_BB64_HALVES=2): EIGHT compute waves -- the four pixel groups times two
+// cout halves, two per SIMD, so that one wave's fragment reads and barrier waits hide behind the other's MFMAs.  Same LDS images, same weight ring,
+// same k order per output: bit-identical.  Measured (scripts/bblab.hip, 32 x 112 x 112): the third tile takes 17 877 shader cycles instead of 19 595
+// (the intermediate write 1 944 instead of 3 057), the whole kernel 126 k instead of 136 k -- and 73.2-74.2 us instead of 71.8-72.1: the in-kernel
+// clock read 1.56 GHz against 1.71.  The package draws 1 370 W of its 1 400 W limit under this kernel (rocm-smi, profiles/r05_power.txt): twelve
+// waves and 55 % more LDS bytes per k-step (both halves read every B fragment) cost the clock what they save in cycles.  Kept as a switch.
+template <int HV>
+__global__ __launch_bounds__((4 * HV + 4) * 64, 1) void bb64_kernel(const BBProblem P) {
     typedef __bf16 T;
-    constexpr int CT = 4, PT1 = 5, PT2 = 4, KK = 9, BQ = 6;
+    constexpr int CT = 4 / HV, NCW = 4 * HV, NP = CT / 2, PT1 = 5, PT2 = 4, KK = 9, BQ = 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,9 +90,9 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         R = min(8, H - oy0); Wc = min(P.Wt, W - ox0);
     };
 
-    if (wave >= 4) {
+    if (wave >= NCW) {
         // ================= loader waves: LDS-DMA only =================
-        const int lw = wave - 4;
+        const int lw = wave - NCW;
         const unsigned lane16 = (unsigned)lane * 16u;
         int t = blockIdx.x;
         if (t >= P.ntiles) return;
@@ -192,10 +199,11 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
     int t = blockIdx.x;
     if (t >= P.ntiles) return;
     const float *bias1 = P.bias1, *bias2 = P.bias2;
-    float b1[16], b2[16];
+    const int pw = HV == 2 ? (wave & 3) : wave, hv = HV == 2 ? (wave >> 2) : 0;            // pixel group, cout half
+    float b1[4 * CT], b2[4 * CT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { b1[i] = bias1[16 * q + i]; b2[i] = bias2[16 * q + i]; }
-    const int aaddr = BB_OFF_A + lane * 16;
+    for (int i = 0; i < 4 * CT; ++i) { b1[i] = bias1[16 * q + 4 * CT * hv + i]; b2[i] = bias2[16 * q + 4 * CT * hv + i]; }
+    const int aaddr = BB_OFF_A + lane * 16 + hv * CT * 1024;
     bf16x8 aq[2][CT], bq[BQ];
     asm volatile("s_barrier" ::: "memory");             // prologue: first image + weight k-steps 0..2 landed
 #pragma unroll
@@ -215,13 +223,13 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         int ba1[PT1], ba2[PT2];
 #pragma unroll
         for (int pt = 0; pt < PT1; ++pt) {
-            const int s0 = (wave * PT1 + pt) * 16 + c, s = s0 < nmid ? s0 : 0;
+            const int s0 = (pw * PT1 + pt) * 16 + c, s = s0 < nmid ? s0 : 0;
             const int r = (int)(((float)s + 0.5f) * inv_mc), x = s - r * MC;
             ba1[pt] = inb + (q >> 1) * BB_INQ + (q & 1) * 16 + (r * 32 + x) * 32;
         }
 #pragma unroll
         for (int pt = 0; pt < PT2; ++pt) {
-            const int s0 = (wave * PT2 + pt) * 16 + c, s = s0 < nout ? s0 : 0;
+            const int s0 = (pw * PT2 + pt) * 16 + c, s = s0 < nout ? s0 : 0;
             const int r = (int)(((float)s + 0.5f) * inv_wc), x = s - r * Wc;
             ba2[pt] = BB_OFF_MID + (q >> 1) * BB_MIDQ + (q & 1) * 16 + (r * 32 + x) * 32;
         }
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
         // ---------------- intermediate: bias + ReLU -> bf16 -> LDS image (zero outside the map) ----------------
 #pragma clang loop unroll(full)
         for (int pt = 0; pt < PT1; ++pt) {
-            const int s = (wave * PT1 + pt) * 16 + c;
+            const int s = (pw * PT1 + pt) * 16 + c;
             const int r = (int)(((float)s + 0.5f) * inv_mc), x = s - r * MC;
             const int my = oy0 - 1 + r, mx = ox0 - 1 + x;
             const bool inside = (unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W;
@@ -270,21 +278,22 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
             // 8 packed dwords (per pixel), not per channel: a lone wave pays every VALU instruction of this block in full
             // ReLU on the PACKED bf16 pair (a negative bf16 is a negative int16: one v_pk_max_i16 per two channels; rounding is
             // monotonic, so relu(bf16(v)) == bf16(relu(v)))
-            u32x4 o0, o1;
+            u32x4 o[NP];                                 // this lane's 8 * NP channels of the pixel: 16-byte pieces hv * NP .. of its quarter entry
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 f32x2 lo = {acc[ct][pt][0] + b1[4 * ct + 0], acc[ct][pt][1] + b1[4 * ct + 1]};
                 f32x2 hi = {acc[ct][pt][2] + b1[4 * ct + 2], acc[ct][pt][3] + b1[4 * ct + 3]};
-                const unsigned w0 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)));
-                const unsigned w1 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
-                if (ct < 2) { o0[2 * ct] = w0; o0[2 * ct + 1] = w1; }
-                else { o1[2 * ct - 4] = w0; o1[2 * ct - 3] = w1; }
+                o[ct >> 1][2 * (ct & 1)] = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)));
+                o[ct >> 1][2 * (ct & 1) + 1] = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
             }
-            if (border && !inside) { o0 = u32x4{0u, 0u, 0u, 0u}; o1 = o0; }      // conv2's zero padding; interior tiles skip the test
+            if (border && !inside) {                     // conv2's zero padding; interior tiles skip the test
+#pragma unroll
+                for (int k = 0; k < NP; ++k) o[k] = u32x4{0u, 0u, 0u, 0u};
+            }
             if (s < nmid) {
-                u32x4 *dst = reinterpret_cast<u32x4 *>(smem + BB_OFF_MID + q * BB_MIDQ + (r * 32 + x) * 32);
-                dst[0] = o0;
-                dst[1] = o1;
+                u32x4 *dst = reinterpret_cast<u32x4 *>(smem + BB_OFF_MID + q * BB_MIDQ + (r * 32 + x) * 32) + hv * NP;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) dst[k] = o[k];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -304,13 +313,14 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
 #pragma clang loop unroll(full)
             for (int pt = 0; pt < PT2; ++pt) {
                 const int j = p2 * PT2 + pt, jr = j + BQ - 1;
-                aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % BB_NSLOT) * BB_ASLOT + pt * 1024);
+                if (pt < CT)
+                    aq[(ph + 1) & 1][pt] = *reinterpret_cast<const bf16x8 *>(smem + aaddr + ((ph + 1) % BB_NSLOT) * BB_ASLOT + pt * 1024);
                 if (jr < 18 * PT2) bq[jr % BQ] = *reinterpret_cast<const bf16x8 *>(smem + ba2[jr % PT2] + BB_OFF2(jr));
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ph & 1][ct], bq[j % BQ], acc[ct][pt], 0, 0, 0);
-                if (jr < 18 * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (pt < CT && jr < 18 * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (pt < CT || jr < 18 * PT2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -323,29 +333,28 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
                 (char *)P.out + ((size_t)b * H * W * P.out_cs + P.out_coff) * 2, 0, (int)((size_t)H * W * P.out_cs * 2), 0x00020000);
 #pragma clang loop unroll(full)
             for (int pt = 0; pt < PT2; ++pt) {
-                const int s = (wave * PT2 + pt) * 16 + c;
+                const int s = (pw * PT2 + pt) * 16 + c;
                 const int r = (int)(((float)s + 0.5f) * inv_wc), x = s - r * Wc;
                 const bool valid = s < nout;
                 const u32x4 *rp = reinterpret_cast<const u32x4 *>(smem + inb + q * BB_INQ + (((valid ? r : 0) + 2) * 32 + (valid ? x : 0) + 2) * 32);
-                const u32x4 r0 = rp[0], r1 = rp[1];
-                u32x4 o0, o1;
+                u32x4 rr[NP], o[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) rr[k] = rp[hv * NP + k];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const unsigned ra = ct < 2 ? r0[2 * ct] : r1[2 * ct - 4], rb = ct < 2 ? r0[2 * ct + 1] : r1[2 * ct - 3];
+                    const unsigned ra = rr[ct >> 1][2 * (ct & 1)], rb = rr[ct >> 1][2 * (ct & 1) + 1];
                     // a bf16 is the upper half of its float: residual channels by shift / mask, no conversion instruction
                     f32x2 lo = {acc[ct][pt][0] + b2[4 * ct + 0] + __builtin_bit_cast(float, ra << 16),
                                 acc[ct][pt][1] + b2[4 * ct + 1] + __builtin_bit_cast(float, ra & 0xffff0000u)};
                     f32x2 hi = {acc[ct][pt][2] + b2[4 * ct + 2] + __builtin_bit_cast(float, rb << 16),
                                 acc[ct][pt][3] + b2[4 * ct + 3] + __builtin_bit_cast(float, rb & 0xffff0000u)};
-                    const unsigned w0 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)));
-                    const unsigned w1 = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
-                    if (ct < 2) { o0[2 * ct] = w0; o0[2 * ct + 1] = w1; }
-                    else { o1[2 * ct - 4] = w0; o1[2 * ct - 3] = w1; }
+                    o[ct >> 1][2 * (ct & 1)] = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)));
+                    o[ct >> 1][2 * (ct & 1) + 1] = bb_relu_pk(__builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
                 }
                 // out-of-range offset for the unused slots: the store is issued unconditionally and dropped by the hardware
                 const unsigned voff = valid ? (unsigned)(((oy0 + r) * W + ox0 + x) * P.out_cs * 2 + 32 * q) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(o0, orsrc, voff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(o1, orsrc, voff + 16u, 0, 0);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(o[k], orsrc, voff + 16u * (unsigned)(hv * NP + k), 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // the loader may now refill this image's buffer
@@ -360,15 +369,18 @@ __global__ __launch_bounds__(512, 1) void bb64_kernel(const BBProblem P) {
 }
 
 static int bb64_launch(pn_ctx *ctx, const BBProblem &P, int num_cus, hipStream_t stream) {
-    static PnLdsAttr attr;
-    if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(bb64_kernel), BB_LDS)) return rc;
+    static PnLdsAttr attr[2];
+    const char *he = getenv("POPNET_BB64_HALVES");   // =2: the eight-compute-wave form (opt-in: 7 % fewer cycles, 2-3 % MORE time -- see the kernel's comment)
+    const int halves = he && atoi(he) == 2 ? 2 : 1;
+    if (int rc = pn_lds_attr(ctx, attr[halves - 1], halves == 2 ? reinterpret_cast<const void *>(bb64_kernel<2>) : reinterpret_cast<const void *>(bb64_kernel<1>), BB_LDS)) return rc;
     // experiment switch: POPNET_BB64_CUS = workgroups of the persistent launch (default: one per CU).  Fewer leave whole CUs to the
     // kernels of other streams while this one runs (a bb64 workgroup owns its CU's LDS).
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("POPNET_BB64_CUS"); cap = e ? atoi(e) : 0; }
     if (cap > 0 && cap < num_cus) num_cus = cap;
     const int grid = P.ntiles < num_cus ? P.ntiles : num_cus;
-    hipLaunchKernelGGL(bb64_kernel, dim3(grid), dim3(512), BB_LDS, stream, P);
+    if (halves == 2) hipLaunchKernelGGL(bb64_kernel<2>, dim3(grid), dim3(768), BB_LDS, stream, P);
+    else hipLaunchKernelGGL(bb64_kernel<1>, dim3(grid), dim3(512), BB_LDS, stream, P);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }

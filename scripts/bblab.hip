@@ -14,6 +14,9 @@ __device__ unsigned long long *g_stamps;
     if ((i) == 0) g_stamps[b_ + 14] = __builtin_amdgcn_s_memrealtime(); if ((i) == 12) g_stamps[b_ + 15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #endif
 #include "bb64_kernel.h"
+#ifndef BBLAB_HV
+#define BBLAB_HV 2          // compute-wave halves (bb64_kernel<HV>): -DBBLAB_HV=1 is the four-compute-wave form
+#endif
 int pn_set_error(pn_ctx *, int code, const char *fmt, ...) { fprintf(stderr, "error %d: %s\n", code, fmt); return code; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
@@ -38,8 +41,8 @@ int main(int argc, char **argv) {
 #ifdef PN_STAMP
     unsigned long long *dst; CK(hipMalloc(&dst, (size_t)grid * 16 * 8)); CK(hipMemset(dst, 0, (size_t)grid * 16 * 8)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst)));
 #endif
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(bb64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS));
-    auto launch = [&]() { hipLaunchKernelGGL(bb64_kernel, dim3(grid), dim3(512), BB_LDS, 0, P); };
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(bb64_kernel<BBLAB_HV>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS));
+    auto launch = [&]() { hipLaunchKernelGGL(bb64_kernel<BBLAB_HV>, dim3(grid), dim3((4 * BBLAB_HV + 4) * 64), BB_LDS, 0, P); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());

@@ -258,7 +258,7 @@ def test_bf16_strip_kernel_equals_generic_kernel_bit_for_bit(gpu, golden, hw, mo
         assert torch.equal(got4_y, ref_y)
 
 
-@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0", "POPNET_NO_BBLOCK=1", "POPNET_NO_TAILFUSE=1", "POPNET_NO_MIX=1", "POPNET_NO_POOLFUSE=1", "POPNET_GENERIC_C64=0", "POPNET_NO_STEMPOOL=1", "POPNET_NO_EMBED3=1", "POPNET_BB64_STATIC=1"])
+@pytest.mark.parametrize("switch", ["POPNET_CONV3_PT14=1", "POPNET_CONV3_PT14=2", "POPNET_CONV3_NBUF2=1", "POPNET_CONV3_RPG8=1", "POPNET_CONV4=1", "POPNET_CONV4=0", "POPNET_NO_BBLOCK=1", "POPNET_NO_TAILFUSE=1", "POPNET_NO_MIX=1", "POPNET_NO_POOLFUSE=1", "POPNET_GENERIC_C64=0", "POPNET_NO_STEMPOOL=1", "POPNET_NO_EMBED3=1", "POPNET_BB64_STATIC=1", "POPNET_BB64_HALVES=2"])
 def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, monkeypatch):
     """The experiment switches of profiles/README.md (224-pixel wave tiles, double-buffered halo images, 8-row tiles on
     14-column maps; conv4_kernel on every / no level; the two layer1 BasicBlocks as two launches each instead of the fused
