@@ -370,8 +370,7 @@ __global__ __launch_bounds__((4 * HV + 4) * 64, 1) void bb64_kernel(const BBProb
 
 static int bb64_launch(pn_ctx *ctx, const BBProblem &P, int num_cus, hipStream_t stream) {
     static PnLdsAttr attr[2];
-    const char *he = getenv("POPNET_BB64_HALVES");   // =2: the eight-compute-wave form (opt-in: 7 % fewer cycles, 2-3 % MORE time -- see the kernel's comment)
-    const int halves = he && atoi(he) == 2 ? 2 : 1;
+    const int halves = P.halves == 2 ? 2 : 1;        // 2 (POPNET_BB64_HALVES=2 when the net was compiled): the eight-compute-wave form -- 7 % fewer cycles, 2-3 % MORE time
     if (int rc = pn_lds_attr(ctx, attr[halves - 1], halves == 2 ? reinterpret_cast<const void *>(bb64_kernel<2>) : reinterpret_cast<const void *>(bb64_kernel<1>), BB_LDS)) return rc;
     // experiment switch: POPNET_BB64_CUS = workgroups of the persistent launch (default: one per CU).  Fewer leave whole CUs to the
     // kernels of other streams while this one runs (a bb64 workgroup owns its CU's LDS).

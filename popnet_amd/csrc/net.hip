@@ -72,6 +72,8 @@ struct Step {
     void *bb_wpack = nullptr;
     float *bb_bias1 = nullptr, *bb_bias2 = nullptr;
     int *bb_tickets = nullptr;       // two zeroed ints: bb64_kernel's tile tickets (BBProblem::tickets)
+    bool bb_static = false;          // POPNET_BB64_STATIC=1 when the net was compiled: tiles by position
+    int bb_halves = 1;               // POPNET_BB64_HALVES=2 when the net was compiled: bb64_kernel<2>
     // STEM
     int out_buf = -1;
     int stem_pool_buf = -1;          // >= 0: the MaxPool2d(3, 2, 1) that follows runs inside the stem launch and writes this buffer (build_yolo)
@@ -650,6 +652,8 @@ int add_bblock(pn_net *n, int ia, int ib) {
     PN_HIP_CHECK(ctx, hipMemcpy(st.bb_bias1, hb[0].data(), 64 * 4, hipMemcpyHostToDevice));
     PN_HIP_CHECK(ctx, hipMemcpy(st.bb_bias2, hb[1].data(), 64 * 4, hipMemcpyHostToDevice));
     if (int rc = dev_alloc(n, (void **)&st.bb_tickets, 256, true)) return rc;
+    st.bb_static = getenv("POPNET_BB64_STATIC") != nullptr;          // experiment switches, read when the net is compiled (A/B runs, bit-identity tests)
+    if (const char *e = getenv("POPNET_BB64_HALVES")) st.bb_halves = atoi(e) == 2 ? 2 : 1;
     n->steps.push_back(st);
     return PN_OK;
 }
@@ -1103,7 +1107,8 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
             P.ntiles = B * P.tiles_per_img;
             P.in_zero_off = (unsigned)((size_t)n->max_batch * ib.H * ib.W * ib.C * n->esize());
             P.in_split = n->x3 ? ib.plane : 0; P.out_split = n->x3 ? ob.plane : 0;
-            P.tickets = (n->x3 || getenv("POPNET_BB64_STATIC")) ? nullptr : st.bb_tickets;      // POPNET_BB64_STATIC=1: blockIdx.x + k * gridDim.x (A/B runs, bit-identity test)
+            P.tickets = (n->x3 || st.bb_static) ? nullptr : st.bb_tickets;      // nullptr: blockIdx.x + k * gridDim.x
+            P.halves = st.bb_halves;
             rc = n->x3 ? pn_launch_bb64x3(ctx, P, stream) : pn_launch_bb64(ctx, P, stream);
         } else {
             rc = pn_launch_conv(ctx, st.launch, stream);

@@ -171,6 +171,7 @@ struct BBProblem {
     // bb64_kernel (round 5): two zero-initialised ints in device memory -- [0] the next tile ticket, [1] the number of workgroups that have finished (the last
     // one resets both, so a replayed graph finds zeros again).  nullptr = the static schedule (tile = blockIdx.x + k * gridDim.x)
     int *tickets;
+    int halves;          // bb64_kernel<halves>: 2 = eight compute waves (opt-in), anything else = four
 };
 int pn_launch_bb64(pn_ctx *ctx, const BBProblem &P, hipStream_t stream);       // bb64_inst.hip
 int pn_launch_bb64x3(pn_ctx *ctx, const BBProblem &P, hipStream_t stream);     // bb64x3_inst.hip (6-row tiles: tiles_per_img = ceil(H / 6) * tiles_x)

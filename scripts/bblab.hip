@@ -35,7 +35,7 @@ int main(int argc, char **argv) {
     BBProblem P; memset(&P, 0, sizeof P);
     P.in = din; P.out = dout; P.wpack = dw; P.bias1 = db; P.bias2 = db + 64; P.B = B; P.H = H; P.W = W; P.in_cs = 64; P.out_cs = 64;
     const int segs = (W + 27) / 28; P.Wt = (W + segs - 1) / segs; P.tiles_x = (W + P.Wt - 1) / P.Wt; P.tiles_per_img = ((H + 7) / 8) * P.tiles_x; P.ntiles = B * P.tiles_per_img;
-    P.in_zero_off = (unsigned)(hin.size() * 2);
+    P.in_zero_off = (unsigned)(hin.size() * 2); P.halves = BBLAB_HV;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int grid = std::min(P.ntiles, prop.multiProcessorCount);
 #ifdef PN_STAMP
