@@ -38,6 +38,63 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+
+class GpuPowerSampler:
+    """Package power and shader clock of the GPU this rank runs on, read from its hwmon files (plain sysfs reads, no privileges) every
+    `period` seconds between start() and stop().  Context for `roofline.frac`: the 2.5 PFLOP/s peak assumes 2.4 GHz, and the conv stack
+    holds the package at ~1.3 kW of its 1.4 kW limit at ~2.07 GHz (profiles/r05_power.txt).  Returns None where the files are absent."""
+
+    def __init__(self, device_index, period=0.004):
+        import glob
+        import threading
+        self.dir, self.period, self._stop, self._thr, self.samples = None, period, threading.Event(), None, []
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for h in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf):
+                if os.path.exists(os.path.join(h, "power1_input")) and os.path.exists(os.path.join(h, "freq1_input")):
+                    self.dir, self.bdf = h, bdf
+        except Exception:                                         # noqa: BLE001 -- no such attributes / no sysfs: the field stays null
+            self.dir = None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return int(f.read().strip())
+
+    def start(self):
+        import threading
+        if self.dir is None:
+            return self
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append((self._read("power1_input") / 1e6, self._read("freq1_input") / 1e6))
+                except (OSError, ValueError):
+                    pass
+                self._stop.wait(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        if self.dir is None or self._thr is None:
+            return None
+        self._stop.set()
+        self._thr.join()
+        if len(self.samples) < 3:
+            return None
+        w = np.array([a for a, _ in self.samples]); f = np.array([b for _, b in self.samples])
+        busy = w > 0.5 * w.max()                                  # the samples taken while the regions ran (the gaps between them idle at ~250 W)
+        try:
+            cap = self._read("power1_cap") / 1e6
+        except (OSError, ValueError):
+            cap = None
+        return {"package_w_median": round(float(np.median(w[busy])), 1), "package_w_max": round(float(w.max()), 1), "package_w_limit": cap,
+                "sclk_mhz_median": round(float(np.median(f[busy])), 0), "sclk_mhz_min": round(float(f[busy].min()), 0), "samples": int(busy.sum()),
+                "what": "hwmon power1_input / freq1_input of %s every %.0f ms through the resident timed regions (samples above half the maximum power); "
+                        "power1_input is the firmware's moving average: regions shorter than ~0.3 s in total (the 20-step form) end before it has risen -- "
+                        "a 3 000-step region reads 1 290-1 310 W at 2 067 MHz (profiles/r05_power.txt)" % (self.bdf, self.period * 1e3)}
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -475,7 +532,11 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
     torch.cuda.synchronize()
 
     REPS = max(1, args.reps)
+    power = GpuPowerSampler(dev.index if dev.index is not None else 0).start() if rank == 0 else None
     runs = {"resident": [region(False) for _ in range(REPS)]}
+    power = power.stop() if power is not None else None
+    if power is not None:
+        power["regions_s"] = round(float(sum(runs["resident"])), 3)
     keep_res, batch_res = keep.cpu(), list(batch_of)
     link = None
     tail_h2d = []
@@ -622,7 +683,7 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
             "roofline": {"bound": "mfma", "kernel": dom["kernel"] + " (dominant convolution instantiation: %.0f of %.0f conv us/step)" % (dom["us_per_step"], conv_ms.value * 1e3 / K),
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"],
-                         "launches_per_step": dom["launches_per_step"],
+                         "launches_per_step": dom["launches_per_step"], "power": power,
                          "conv_stack": {"achieved": round(achieved, 2), "frac": round(achieved / peak, 4), "launches_per_step": conv_n.value // max(K, 1),
                                         "ms_per_step": round(conv_ms.value / K, 4), "tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
                                         "stem_pool_ms_per_step": round(other_ms.value / K, 4), "by_kernel": kernels},
