@@ -146,14 +146,11 @@ __global__ __launch_bounds__((4 * HV + 4) * 64, 1) void bb64_kernel(const BBProb
         int ticket = 0;
         // (hybrids -- the first tiles of a workgroup by position, only its last 1, 2 or 3 by ticket -- measured no better than the static schedule:
         //  profiles/r05_notes.txt)
-        auto claim = [&]() -> int {
-#ifdef BB_TICKET_FAKE             // timing experiment: the ticket protocol without the atomics (the static sequence through LDS)
-            return (ticket ? ticket : t) + (int)gridDim.x;
-#else
-            return 2 * (int)gridDim.x + atomicAdd(P.tickets, 1);
-#endif
-        };
-        if (ticketer) ticket = t + (int)gridDim.x;             // the first two tiles of a workgroup by position: the prologue waits for no atomic
+        // The first TWO tiles of a workgroup are its position (the prologue waits for no atomic).  Launches with fewer than four tiles per workgroup
+        // (56 x 56 maps: 448 tiles on 256 workgroups) keep the static schedule altogether (net.hip passes no counters): with the second tile a ticket
+        // YoloPoseNet lost 1.5 % (96.1 / 95.9 / 96.3 k against 98.0 / 97.7 / 96.4 k frames/s, same box, profiles/r05_notes.txt).
+        auto claim = [&]() -> int { return 2 * (int)gridDim.x + atomicAdd(P.tickets, 1); };
+        if (ticketer) ticket = t + (int)gridDim.x;
 #pragma unroll
         for (int j = 0; j < 24; ++j) dma_in(t, 0, n0 + j);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1107,7 +1107,7 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
             P.ntiles = B * P.tiles_per_img;
             P.in_zero_off = (unsigned)((size_t)n->max_batch * ib.H * ib.W * ib.C * n->esize());
             P.in_split = n->x3 ? ib.plane : 0; P.out_split = n->x3 ? ob.plane : 0;
-            P.tickets = (n->x3 || st.bb_static) ? nullptr : st.bb_tickets;      // nullptr: blockIdx.x + k * gridDim.x
+            P.tickets = (n->x3 || st.bb_static || P.ntiles < 4 * ctx->num_cus) ? nullptr : st.bb_tickets;      // nullptr: blockIdx.x + k * gridDim.x
             P.halves = st.bb_halves;
             rc = n->x3 ? pn_launch_bb64x3(ctx, P, stream) : pn_launch_bb64(ctx, P, stream);
         } else {

@@ -286,13 +286,19 @@ def test_bf16_optional_kernel_variants_are_bit_identical(gpu, golden, switch, mo
     assert torch.isfinite(got_y).all() and torch.equal(got_y, ref_y), switch
 
 
-def test_bb64_tile_tickets_are_left_at_zero_for_the_next_launch(gpu, golden):
-    """bb64_kernel hands its tiles out by ticket (round 5); the last workgroup to finish resets the two counters, so the same net --
-    eager or as a replayed graph -- gives the same maps launch after launch (a stale counter would skip every tile past the first
-    per workgroup: 32 frames of 224x224 are 1792 tiles for 256 workgroups)."""
+def test_bb64_tile_tickets_are_left_at_zero_for_the_next_launch(gpu, golden, monkeypatch):
+    """bb64_kernel hands its tiles out by ticket (round 5; launches with at least four tiles per workgroup); the last workgroup to sign
+    off resets the two counters, so the same net -- eager or as a replayed graph -- gives the same maps launch after launch (a stale
+    counter would skip every tile past the second per workgroup: 32 frames of 224x224 are 1792 tiles for 256 workgroups), and the
+    maps of the static schedule (POPNET_BB64_STATIC=1, read when the net is compiled) bit for bit."""
     x = torch.from_numpy(np.random.default_rng(61).normal(0, 1, (32, 1, 224, 224)).astype(np.float32)).to(gpu)
+    monkeypatch.setenv("POPNET_BB64_STATIC", "1")
+    static = [t.clone() for t in _rtpose(golden, "bf16")(x)[0]]
+    monkeypatch.delenv("POPNET_BB64_STATIC")
     net = _rtpose(golden, "bf16")
     first = [t.clone() for t in net(x)[0]]
+    for a, b, name in zip(first, static, ("paf", "heat", "z")):
+        assert torch.equal(a, b), ("static schedule", name)
     for _ in range(4):
         again = [t.clone() for t in net(x)[0]]
         for a, b, name in zip(again, first, ("paf", "heat", "z")):
