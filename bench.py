@@ -42,7 +42,9 @@ import torch  # noqa: E402
 class GpuPowerSampler:
     """Package power and shader clock of the GPU this rank runs on, read from its hwmon files (plain sysfs reads, no privileges) every
     `period` seconds between start() and stop().  Context for `roofline.frac`: the 2.5 PFLOP/s peak assumes 2.4 GHz, and the conv stack
-    holds the package at ~1.3 kW of its 1.4 kW limit at ~2.07 GHz (profiles/r05_power.txt).  Returns None where the files are absent."""
+    holds the package at ~1.3 kW of its 1.4 kW limit at ~2.07 GHz (profiles/r05_power.txt).  Returns None where the files are absent.
+    NEVER runs during a region that feeds `value` (its polling thread shares the GIL with the enqueue loop): bench.py samples
+    one extra untimed region of >= 0.9 s and the pn_mfma_sustained probe."""
 
     def __init__(self, device_index, period=0.004):
         import glob
@@ -65,10 +67,11 @@ class GpuPowerSampler:
         import threading
         if self.dir is None:
             return self
+        self._t0 = time.perf_counter()
         def loop():
             while not self._stop.is_set():
                 try:
-                    self.samples.append((self._read("power1_input") / 1e6, self._read("freq1_input") / 1e6))
+                    self.samples.append((time.perf_counter() - self._t0, self._read("power1_input") / 1e6, self._read("freq1_input") / 1e6))
                 except (OSError, ValueError):
                     pass
                 self._stop.wait(self.period)
@@ -76,24 +79,25 @@ class GpuPowerSampler:
         self._thr.start()
         return self
 
-    def stop(self):
+    def stop(self, what=""):
+        """-> {"package_w_median", "sclk_mhz_median", ...} over the SECOND half of the sampled interval (power1_input is the firmware's
+        moving average: it needs ~0.3 s to rise), or None when the interval was shorter than 0.3 s / the files are absent."""
         if self.dir is None or self._thr is None:
             return None
         self._stop.set()
         self._thr.join()
-        if len(self.samples) < 3:
+        span = self.samples[-1][0] if self.samples else 0.0
+        late = [(w, f) for t, w, f in self.samples if t >= 0.5 * span]
+        if span < 0.3 or len(late) < 3:
             return None
-        w = np.array([a for a, _ in self.samples]); f = np.array([b for _, b in self.samples])
-        busy = w > 0.5 * w.max()                                  # the samples taken while the regions ran (the gaps between them idle at ~250 W)
+        w = np.array([a for a, _ in late]); f = np.array([b for _, b in late])
         try:
             cap = self._read("power1_cap") / 1e6
         except (OSError, ValueError):
             cap = None
-        return {"package_w_median": round(float(np.median(w[busy])), 1), "package_w_max": round(float(w.max()), 1), "package_w_limit": cap,
-                "sclk_mhz_median": round(float(np.median(f[busy])), 0), "sclk_mhz_min": round(float(f[busy].min()), 0), "samples": int(busy.sum()),
-                "what": "hwmon power1_input / freq1_input of %s every %.0f ms through the resident timed regions (samples above half the maximum power); "
-                        "power1_input is the firmware's moving average: regions shorter than ~0.3 s in total (the 20-step form) end before it has risen -- "
-                        "a 3 000-step region reads 1 290-1 310 W at 2 067 MHz (profiles/r05_power.txt)" % (self.bdf, self.period * 1e3)}
+        return {"package_w_median": round(float(np.median(w)), 1), "package_w_max": round(float(w.max()), 1), "package_w_limit": cap,
+                "sclk_mhz_median": round(float(np.median(f)), 0), "sclk_mhz_min": round(float(f.min()), 0), "samples": len(late), "sampled_s": round(span, 3),
+                "what": "hwmon power1_input / freq1_input of %s every %.0f ms, second half of %s" % (self.bdf, self.period * 1e3, what)}
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -485,31 +489,53 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
 
     keep_records = {"on": True}
 
+    AHEAD = PIPE if POOL >= 2 else 0                             # hand-over regions: transfers posted this many batches ahead of their step
+
     def step(k, h2d):
         sl = se._tickets % PIPE                                  # the slot this submit will use
-        if h2d:                                                  # PCIe-inclusive: 19.7 MB per batch, copied on the slot's copy stream
-            i = k % NIN                                          # into its next input buffer (under the slot's current step)
-            t = se.submit_host(pinned[i])
+        if h2d:                                                  # PCIe-inclusive: 19.7 MB per batch, copied on the copy stream into the
+            i = k % NIN                                          # slot's next input buffer (under the kernels of earlier batches)
+            if AHEAD:
+                t = se.submit_posted()                           # batch k: posted AHEAD steps ago (the first AHEAD before the region opened)
+                se.post_host(pinned[(k + AHEAD) % NIN])          # ... and the transfer of batch k + AHEAD leaves now
+            else:
+                t = se.submit_host(pinned[i])
         else:                                                    # resident: buffer j of the slot holds batch sl * POOL + j
             j = (k // PIPE) % POOL
             i = sl * POOL + j
             t = se.submit(j)
-        batch_of[k] = i
+        batch_of[k % K] = i
         if keep_records["on"]:                                   # bench bookkeeping (consistency check, the gather), not the product path
             with torch.cuda.stream(se.stream(t)):
-                keep[k].copy_(se.wires[t % PIPE] if se.wire else se.records(t), non_blocking=True)
+                keep[k % K].copy_(se.wires[t % PIPE] if se.wire else se.records(t), non_blocking=True)
 
     host_enqueue_s = {}
 
-    def region(h2d):
-        """K steps, barrier + device sync on both sides, max over ranks.  Returns seconds."""
+    def region(h2d, steps=None):
+        """K steps, barrier + device sync on both sides, max over ranks.  Returns seconds.
+        Hand-over regions stream: the transfers of the first AHEAD batches are posted BEFORE the region opens and the region posts the
+        transfers of the AHEAD batches after its last step (K transfers and K steps inside the window either way) -- a live stream's
+        next frames are already on the link while the previous ones finish."""
+        n = K if steps is None else steps
+        if h2d and AHEAD:
+            se.drop_posted()
+            for a in range(AHEAD):
+                se.post_host(pinned[a % NIN])
         if dist_active:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(K):
+        for k in range(n):
             step(k, h2d)
-        host_enqueue_s[h2d] = time.perf_counter() - t0           # how long the host needed to enqueue the K steps
+        host_enqueue_s[h2d] = (time.perf_counter() - t0) * K / n  # how long the host needed to enqueue K steps
+        if h2d and AHEAD and not dist_active:
+            # SURVEY 8(d): "... to last record on host" -- the window closes when the last step's records have landed in pinned host memory
+            # (every slot stream drained); the AHEAD transfers posted for the batches AFTER this window are drained untimed below
+            for st in streams:
+                st.synchronize()
+            el = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            return el
         se.join()
         if dist_active:
             dist.all_gather_into_tensor(gathered, keep.view(K * BATCH, witem))
@@ -524,7 +550,10 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
         return el
 
     se.capture()
-    for i in range(max(W, 2 * PIPE)):
+    # W untimed steps as asked -- and never fewer than 30: the first 20-step region of a fresh process ran 8-9 % under the median on clocks
+    # that had not settled (r05 children, r06 main leg 62.9 k against 68.3 k); `warmup_steps_run` in the line says what ran
+    WARM = max(W, 30)
+    for i in range(WARM):
         step(i % K, False)
     se.join()
     if dist_active:
@@ -532,12 +561,29 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
     torch.cuda.synchronize()
 
     REPS = max(1, args.reps)
-    power = GpuPowerSampler(dev.index if dev.index is not None else 0).start() if rank == 0 else None
-    runs = {"resident": [region(False) for _ in range(REPS)]}
-    power = power.stop() if power is not None else None
-    if power is not None:
-        power["regions_s"] = round(float(sum(runs["resident"])), 3)
+    runs = {"resident": [region(False) for _ in range(REPS)]}       # nothing else runs in this process while these are timed (no sampler thread: ADVICE r05)
     keep_res, batch_res = keep.cpu(), list(batch_of)
+    # power / clock of the SAME resident region, sampled through one extra UNTIMED repetition long enough for the firmware's moving
+    # average (>= 0.9 s), and the box's sustained matrix-core ceiling (pn_mfma_sustained: nothing but MFMAs on random bf16, 1.5 s)
+    power, sustained = None, None
+    if rank == 0 and world == 1 and not args.no_power:
+        per_step = float(np.median(runs["resident"])) / K
+        nlong = max(K, int(0.9 / max(per_step, 1e-6)) + 1)
+        keep_records["on"] = False
+        smp = GpuPowerSampler(dev.index if dev.index is not None else 0).start()
+        t_long = region(False, steps=nlong)
+        power = smp.stop("one untimed %d-step repetition of the resident region (%.2f s, %.1f frames/s)" % (nlong, t_long, nlong * BATCH / t_long))
+        keep_records["on"] = True
+        region(False)                                            # restores keep / batch_of to a K-step region's (the checks below read them)
+        keep_res, batch_res = keep.cpu(), list(batch_of)
+        tf, ghz = C.c_double(), C.c_double()
+        smp = GpuPowerSampler(dev.index if dev.index is not None else 0).start()
+        rc_ = _lib.lib().pn_mfma_sustained(engine.ctx.handle, 1.5, 4, C.byref(tf), C.byref(ghz), _lib.current_stream_ptr(dev))
+        torch.cuda.synchronize()
+        sp = smp.stop("the pn_mfma_sustained probe")
+        if rc_ == 0:
+            sustained = {"tflops": round(tf.value, 1), "in_kernel_ghz": round(ghz.value, 3), "power": sp,
+                         "what": "pn_mfma_sustained: v_mfma_f32_16x16x32_bf16 only, random bf16 operands, 4 waves per SIMD on every CU, back to back for 1.5 s; the last 20 launches' rate"}
     link = None
     tail_h2d = []
     if want_h2d:
@@ -550,6 +596,7 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
         keep_records["on"] = bool(dist_active)
         runs["h2d"] = [region(True) for _ in range(REPS)]
         keep_records["on"] = True
+        se.drop_posted()
         # ... so the records of the TIMED hand-over regions are checked too: what the last PIPE steps of the last timed region
         # left in the slots' pinned host buffers must equal what the same batches gave in the resident regions
         if not dist_active:
@@ -666,7 +713,7 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
             return round(total_frames / sec, 2)
         out = {
             "metric": "depth-frames/sec end-to-end (480x640)", "value": rate(elapsed),
-            "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "warmup_steps_run": WARM,
             "ms_per_step": round(elapsed / K * 1e3, 4),
             "value_stat": {"what": "median of %d repetitions of the %d-step timed region" % (REPS, K), "min": rate(max(runs["resident"])), "max": rate(min(runs["resident"])),
                            "runs": [rate(v) for v in runs["resident"]]},
@@ -683,7 +730,17 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
             "roofline": {"bound": "mfma", "kernel": dom["kernel"] + " (dominant convolution instantiation: %.0f of %.0f conv us/step)" % (dom["us_per_step"], conv_ms.value * 1e3 / K),
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"],
-                         "launches_per_step": dom["launches_per_step"], "power": power,
+                         "launches_per_step": dom["launches_per_step"],
+                         # flat scalars (the driver's record keeps scalars of this object): the spec-peak `frac` above stays what it was; next to it
+                         # the ceiling THIS box sustains on nothing but MFMAs and the package power / clock of the timed region
+                         "peak_sustained_tflops": sustained["tflops"] if sustained else None,
+                         "frac_of_sustained": round(dom["tflops"] / sustained["tflops"], 4) if sustained and sustained["tflops"] > 0 else None,
+                         "peak_sustained_ghz": sustained["in_kernel_ghz"] if sustained else None,
+                         "peak_sustained_power_w": (sustained.get("power") or {}).get("package_w_median") if sustained else None,
+                         "power_w_median": power["package_w_median"] if power else None, "power_w_limit": power["package_w_limit"] if power else None,
+                         "sclk_mhz_median": power["sclk_mhz_median"] if power else None,
+                         "traffic_commit": (traffic_source or {}).get("commit"), "traffic_measured_at": (traffic_source or {}).get("measured_at"),
+                         "power": power, "sustained": sustained,
                          "conv_stack": {"achieved": round(achieved, 2), "frac": round(achieved / peak, 4), "launches_per_step": conv_n.value // max(K, 1),
                                         "ms_per_step": round(conv_ms.value / K, 4), "tflops_inside_timed_region": round(conv_flops.value / elapsed / 1e12 / world, 2),
                                         "stem_pool_ms_per_step": round(other_ms.value / K, 4), "by_kernel": kernels},
@@ -703,7 +760,10 @@ def pipelined_leg(args, dev, world, rank, dist, net, precision, want_h2d, dist_a
             out["h2d_inclusive"] = {"value": rate(med["h2d"]), "unit": "frames/s", "ms_per_step": round(med["h2d"] / K * 1e3, 4),
                                     "min": rate(max(runs["h2d"])), "max": rate(min(runs["h2d"])), "runs": [rate(v) for v in runs["h2d"]],
                                     "fraction_of_value": round(elapsed / med["h2d"], 4), "host_link": link,
-                                    "what": "same region, every batch copied from pinned host memory inside the region (StreamingEngine.submit_host: %.1f MB per step over PCIe on the copy stream, into the slot's next input buffer while its current step runs): first H2D enqueue to last record on host, median of %d" % (BATCH * 640 * 480 * 2 / 1e6, REPS)}
+                                    "posted_ahead": AHEAD,
+                                    "what": "same region, every batch handed over from pinned host memory (StreamingEngine.post_host / submit_posted: %.1f MB per step over PCIe on the copy stream into the slot's next input buffer). "
+                                            "Streaming form: a batch's transfer is posted %d steps ahead of its step, so the first %d transfers leave before the region opens and the region posts the %d that follow its last step "
+                                            "-- K transfers posted and K steps run inside the window, which closes when the last step's records are in pinned host memory; median of %d" % (BATCH * 640 * 480 * 2 / 1e6, AHEAD, AHEAD, AHEAD, REPS)}
     se_engine, host0 = engine, depth_host
     return {"out": out, "engine": se_engine, "depth_host": host0, "se": se}
 
@@ -720,6 +780,7 @@ def main():
                     help="rtpose = rtpose_light3d + PAF parsing (the headline workload); yolo = YoloPoseNet + box decode (SURVEY 8a rows 7, 12)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive passes (inputs handed over from pinned host memory)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fidelity / multi-person legs (profiling runs)")
+    ap.add_argument("--no-power", action="store_true", help="skip the untimed power-sampled repetition and the sustained-MFMA probe (child legs, profiling runs)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight per GPU (engines on separate HIP streams)")
     ap.add_argument("--pool", type=int, default=6, help="distinct input batches per slot (pipeline x pool x 19.7 MB should exceed the 256 MB Infinity Cache)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region per input mode; the median is reported")
@@ -805,8 +866,9 @@ def main():
             # torch.distributed.run launcher; its rank must not survive and keep the GPU), and the headline line is printed regardless
             import signal
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--reps", str(args.reps),
-                   "--pipeline", str(args.pipeline), "--pool", str(args.pool), "--no-extras", "--no-cpu-baseline"] + extra
+            # a freshly started child's first region ran on clocks that had not settled (r05: runs[0] 9 % under the median): >= 30 untimed steps first
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(max(args.warmup, 30)), "--reps", str(args.reps),
+                   "--pipeline", str(args.pipeline), "--pool", str(args.pool), "--no-extras", "--no-cpu-baseline", "--no-power"] + extra
             try:
                 p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
             except OSError as e:

@@ -60,6 +60,12 @@ int pn_abi_version(void);
  * switches POPNET_ABLATE_SKIP / POPNET_X3_BF16_CONVS are compiled in and can change results), 0 for the shipped library, which
  * honours no result-changing environment variable.  bench.py refuses to time a lab build. */
 int pn_build_experiments(void);
+/* Measurement aid (bench.py `roofline.peak_sustained_tflops`; no reference counterpart -- the reference has no device code): runs a loop of
+ * nothing but v_mfma_f32_16x16x32_bf16 on random bf16 operands (`waves_per_simd` waves on every SIMD of every CU, no memory traffic)
+ * back to back for `seconds` and reports what the LAST batch of launches sustained, i.e. the matrix-core ceiling of THIS box at the
+ * clock its power limit allows, next to the 2.5 PFLOP/s spec figure; *in_kernel_ghz (may be NULL) = median shader clock inside the
+ * kernel (s_memtime / s_memrealtime).  Synchronises the stream. */
+int pn_mfma_sustained(pn_ctx *ctx, double seconds, int waves_per_simd, double *tflops, double *in_kernel_ghz, void *hip_stream);
 pn_ctx *pn_create(int device_id);
 void pn_destroy(pn_ctx *ctx);
 /* Copies the last error message of this context into buf (NUL-terminated). Returns its length. */

@@ -82,6 +82,7 @@ _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 _SIGNATURES = {
     "pn_abi_version": (_i, []),
     "pn_build_experiments": (_i, []),
+    "pn_mfma_sustained": (_i, [_vp, _d, _i, C.POINTER(_d), C.POINTER(_d), _vp]),
     "pn_create": (_vp, [_i]),
     "pn_destroy": (None, [_vp]),
     "pn_last_error": (_i, [_vp, C.c_char_p, _sz]),

@@ -1861,32 +1861,34 @@ __global__ void avgpool_fwd_kernel(const float *__restrict__ x, int H, int W, in
     const int pp = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (pp >= Ho * Wo) return;
     const int oy = pp / Wo, ox = pp - oy * Wo;
-    const size_t plane = blockIdx.y;
-    const size_t i = plane * Ho * Wo + pp;
-    (void)total;
-    const float *xp = x + plane * H * W;
-    float s = 0.f;
-    for (int ky = 0; ky < 3; ++ky)
-        for (int kx = 0; kx < 3; ++kx) {
-            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) s += xp[(size_t)iy * W + ix];
-        }
-    y[i] = s / 9.f;
+    const size_t planes = total / ((size_t)Ho * Wo);
+    for (size_t plane = blockIdx.y; plane < planes; plane += gridDim.y) {       // grid.y = min(planes, 65535): any plane count
+        const size_t i = plane * Ho * Wo + pp;
+        const float *xp = x + plane * H * W;
+        float s = 0.f;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) s += xp[(size_t)iy * W + ix];
+            }
+        y[i] = s / 9.f;
+    }
 }
 
 __global__ void avgpool_bwd_kernel(const float *__restrict__ dy, int H, int W, int Ho, int Wo, size_t total, float *__restrict__ dx) {
     const int pp = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (pp >= H * W) return;
     const int iy = pp / W, ix = pp - iy * W;
-    const size_t plane = blockIdx.y;
-    const size_t i = plane * H * W + pp;
-    (void)total;
-    const float *dp = dy + plane * Ho * Wo;
-    float s = 0.f;
-    for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy)         // outputs whose window [2oy-1, 2oy+1] holds iy
-        for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox)
-            if (oy < Ho && ox < Wo) s += dp[(size_t)oy * Wo + ox];
-    dx[i] = s / 9.f;
+    const size_t planes = total / ((size_t)H * W);
+    for (size_t plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+        const size_t i = plane * H * W + pp;
+        const float *dp = dy + plane * Ho * Wo;
+        float s = 0.f;
+        for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy)         // outputs whose window [2oy-1, 2oy+1] holds iy
+            for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox)
+                if (oy < Ho && ox < Wo) s += dp[(size_t)oy * Wo + ox];
+        dx[i] = s / 9.f;
+    }
 }
 
 // Heads: s = sigmoid(v); out = kind ? (s - 0.5) * 4 : s  (rtpose_light3d.py:335-337), written into a channel slice of the
@@ -2345,8 +2347,7 @@ int pn_avgpool3s2_forward(pn_ctx *ctx, const float *x_dev, float *y_dev, int pla
     if (!x_dev || !y_dev || planes < 1 || H < 1 || W < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_avgpool3s2_forward: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)planes * Ho * Wo;
-    if (planes > 65535) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_avgpool3s2_forward: more than 65535 planes");
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((Ho * Wo + 255) / 256), (unsigned)planes), dim3(256), 0, (hipStream_t)hip_stream, x_dev, H, W, Ho, Wo, total, y_dev);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((Ho * Wo + 255) / 256), (unsigned)std::min(planes, 65535)), dim3(256), 0, (hipStream_t)hip_stream, x_dev, H, W, Ho, Wo, total, y_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }
@@ -2356,8 +2357,7 @@ int pn_avgpool3s2_backward(pn_ctx *ctx, const float *dy_dev, float *dx_dev, int 
     if (!dy_dev || !dx_dev || planes < 1 || H < 1 || W < 1) return pn_set_error(ctx, PN_ERR_INVALID, "pn_avgpool3s2_backward: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)planes * H * W;
-    if (planes > 65535) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_avgpool3s2_backward: more than 65535 planes");
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)planes), dim3(256), 0, (hipStream_t)hip_stream, dy_dev, H, W, Ho, Wo, total, dx_dev);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)std::min(planes, 65535)), dim3(256), 0, (hipStream_t)hip_stream, dy_dev, H, W, Ho, Wo, total, dx_dev);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;
 }

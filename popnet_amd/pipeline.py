@@ -358,6 +358,7 @@ class StreamingEngine:
         self._copied = [[torch.cuda.Event() for _ in range(self.pool)] for _ in range(self.depth)]
         self._released = [[None] * self.pool for _ in range(self.depth)]
         self._next_buf = [0] * self.depth
+        self._posted = []                                      # (slot, buffer) of the batches posted ahead by post_host, oldest first
         self.graphs = [[None] * self.pool for _ in range(self.depth)]
         self._want_graph = bool(graph)
         self._tickets = 0
@@ -411,11 +412,15 @@ class StreamingEngine:
         self._tickets += 1
         return t
 
-    def submit_host(self, host_batch, eager=False):
-        """Host hand-over: copies a pinned host batch into the slot's NEXT input buffer on the slot's copy stream -- ordered only
-        after the step that last read that buffer, so with pool >= 2 the PCIe transfer of this slot's next batch runs under
-        the kernels of its current one -- and runs the step once the copy has landed.  Returns the ticket."""
-        s = self._tickets % self.depth
+    def post_host(self, host_batch):
+        """First half of the host hand-over: enqueues the PCIe transfer of a pinned host batch into the NEXT input buffer of the
+        slot that will run it -- the slot of ticket `tickets + posted` -- on the copy stream, ordered only after the step that last
+        read that buffer.  A streaming caller posts batch k + depth when it submits batch k, so a transfer is always in flight under
+        the kernels of earlier batches (also across the start of a timed region: the frames of a live stream do not wait for the
+        previous ones to finish).  At most depth * (pool - 1) batches may be posted ahead.  Returns the number now posted."""
+        if len(self._posted) >= self.depth * max(1, self.pool - 1):
+            raise _lib.PopnetError("StreamingEngine.post_host: %d batches already posted (depth %d, pool %d)" % (len(self._posted), self.depth, self.pool))
+        s = (self._tickets + len(self._posted)) % self.depth
         j = self._next_buf[s]
         self._next_buf[s] = (j + 1) % self.pool
         cs = self.copy_streams[s]
@@ -424,12 +429,34 @@ class StreamingEngine:
         with torch.cuda.stream(cs):
             self.inputs[s][j][:len(host_batch)].copy_(host_batch, non_blocking=True)
             self._copied[s][j].record(cs)
+        self._posted.append((s, j))
+        return len(self._posted)
+
+    def submit_posted(self, eager=False):
+        """Second half: runs the oldest posted batch on its slot once its transfer has landed.  Returns the ticket."""
+        if not self._posted:
+            raise _lib.PopnetError("StreamingEngine.submit_posted: nothing posted")
+        s, j = self._posted.pop(0)
+        assert s == self._tickets % self.depth
         self.streams[s].wait_event(self._copied[s][j])
         t = self.submit(j, eager)
         if self._released[s][j] is None:
             self._released[s][j] = torch.cuda.Event()
         self._released[s][j].record(self.streams[s])
         return t
+
+    def drop_posted(self):
+        """Forgets the batches posted but not submitted (their transfers still complete; the buffers are simply overwritten later)."""
+        self._posted = []
+
+    def submit_host(self, host_batch, eager=False):
+        """Host hand-over: copies a pinned host batch into the slot's NEXT input buffer on the slot's copy stream -- ordered only
+        after the step that last read that buffer, so with pool >= 2 the PCIe transfer of this slot's next batch runs under
+        the kernels of its current one -- and runs the step once the copy has landed.  Returns the ticket."""
+        if self._posted:
+            raise _lib.PopnetError("StreamingEngine.submit_host: batches are posted ahead (post_host); use submit_posted")
+        self.post_host(host_batch)
+        return self.submit_posted(eager)
 
     def wait(self, ticket):
         self.events[ticket % self.depth].synchronize()

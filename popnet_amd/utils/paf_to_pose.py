@@ -119,9 +119,18 @@ def check_status(fr):
                                % (int(fr['status']), _lib.PN_MAX_PEAKS_PER_JOINT, _lib.PN_MAX_PERSONS))
 
 
+def _device_of(*inputs):
+    """The device the kernels run on: that of the first CUDA tensor among the inputs (a map that already lives on another GPU is parsed
+    there, on that device's context and current stream -- ADVICE r05), else the current device."""
+    for t in inputs:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def paf_to_pose(heatmaps, pafs, config):
     """heatmaps [h,w,J+1], pafs [h,w,2L]: float32 HWC ndarrays (or CUDA tensors) of one frame."""
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = _device_of(heatmaps, pafs)
     hm = torch.as_tensor(np.ascontiguousarray(heatmaps) if isinstance(heatmaps, np.ndarray) else heatmaps)
     pf = torch.as_tensor(np.ascontiguousarray(pafs) if isinstance(pafs, np.ndarray) else pafs)
     hm = hm.to(dev, torch.float32).permute(2, 0, 1)[None].contiguous()
@@ -144,7 +153,7 @@ def NMS(heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=F
         raise _lib.PopnetError("NMS: only bool_refine_center=True, bool_gaussian_filt=False is built (the reference's defaults)")
     if int(upsampFactor) != upsampFactor or int(upsampFactor) != 8:
         raise _lib.PopnetError("NMS: built for upsampFactor = 8 (MODEL.DOWNSAMPLE)")
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = _device_of(heatmaps)
     hm = torch.as_tensor(np.ascontiguousarray(heatmaps) if isinstance(heatmaps, np.ndarray) else heatmaps)
     nk = int(config.MODEL.NUM_KEYPOINTS)
     if hm.dim() != 3 or hm.shape[2] < nk:

@@ -598,6 +598,38 @@ def test_yolo_decode_bit_exact_vs_reference_golden(gpu, golden, seed):
         assert np.array_equal(np.array(v[i], bool).reshape(-1, 15), golden.yolo["s%d_%d_vis" % (seed, i)])
 
 
+def test_yolo_decode_inplace_reproduces_the_reference_side_effect(gpu):
+    """parse_prior_pose(..., inplace=True): the caller's tensor ends up holding what the reference leaves in it (prior_pose_align.py:22-52,
+    oracle.parse_yolo.decode_maps) bit for bit, a 3-D input gains its batch dimension, and a SECOND call then decodes the decoded maps --
+    the double application SURVEY Appendix B records for the reference."""
+    from oracle import parse_yolo as O
+    from popnet_amd.utils.prior_pose_align import parse_prior_pose
+    pm = yolo_maps(31)
+    t = torch.from_numpy(pm.copy()).to(gpu)
+    b0, h0, v0 = parse_prior_pose(t.clone(), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    b1, h1, v1 = parse_prior_pose(t, YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5, inplace=True)
+    assert sum(len(x) for x in b1) > 0
+    for i in range(pm.shape[0]):                                             # same results as the non-mutating call ...
+        assert np.array_equal(np.array(b0[i]), np.array(b1[i])) and np.array_equal(np.array(h0[i]), np.array(h1[i])) and np.array_equal(np.array(v0[i]), np.array(v1[i]))
+    dec = O.decode_maps(pm, YOLO_ANCHORS, 15, 3, 2)                         # ... and the reference's decoded maps left behind
+    assert np.array_equal(t.cpu().numpy().reshape(dec.shape), dec)
+    # second call: decodes the decoded maps, like the reference run twice (= the oracle on the mutated array)
+    rb, rh, rv = O.parse_prior_pose(dec.reshape(pm.shape).copy(), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5)
+    b2, h2, v2 = parse_prior_pose(t, YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5, inplace=True)
+    differs = False
+    for i in range(pm.shape[0]):
+        assert len(b2[i]) == len(rb[i])
+        if len(b2[i]):
+            assert np.array_equal(np.array(b2[i]), np.array(rb[i])) and np.array_equal(np.array(h2[i]), np.array(rh[i]))
+        differs = differs or len(b2[i]) != len(b1[i]) or (len(b2[i]) and not np.array_equal(np.array(b2[i]), np.array(b1[i])))
+    assert differs
+    one = torch.from_numpy(pm[0].copy()).to(gpu)                             # 3-D input: unsqueezed in place like posemaps.unsqueeze_(0)
+    parse_prior_pose(one, YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5, inplace=True)
+    assert one.dim() == 4 and np.array_equal(one.cpu().numpy().reshape(dec[:1].shape), dec[:1])
+    with pytest.raises(_lib.PopnetError, match="contiguous float32"):
+        parse_prior_pose(t.double(), YOLO_ANCHORS, 15, 224, 224, 3, 2, 0.5, 0.5, inplace=True)
+
+
 def test_yolo_decode_dense_batch_vs_oracle(gpu):
     from oracle import parse_yolo as O
     from popnet_amd.utils.prior_pose_align import parse_prior_pose
