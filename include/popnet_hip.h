@@ -350,6 +350,33 @@ int pn_slice_copy(pn_ctx *ctx, const float *src_dev, int src_ld, float *dst_dev,
 int pn_sgd_nesterov(pn_ctx *ctx, float *param_dev, const float *grad_dev, float *momentum_buf_dev, size_t n, float lr,
                     float momentum, float weight_decay, int first_step, float grad_scale, void *hip_stream);
 
+/* ---- training step on NHWC [hi | lo] bf16 planes (round 6; csrc/trainx.hip) -------------------------------------------------
+ * One object runs forward + loss + backward of rtpose_light3d(15, 14, 2, input_dim = 1) in train mode for ONE batch shape:
+ * the per-batch body of tpm/train_rtpose_light3d_kdh3d_mpaug.py:160-180 (CR) up to (not including) optimizer.step(), i.e.
+ * model(img) (tpm/lib/network/rtpose_light3d.py:326-356, BatchNorm on batch statistics, running statistics updated),
+ * rtpose_light3d_loss_fgweight (tpm/lib/network/losses.py:65-106) and loss.backward().  Split-bf16 arithmetic (PN_PREC_BF16X3:
+ * 16 significant bits per operand, fp32 accumulate); forward and data-gradient convolutions run the inference kernels
+ * (conv3_kernel / conv4_kernel / conv_mfma_kernel), the weight gradient a pixel-K MFMA GEMM (trainx_wgrad.h).
+ * Parameters and gradients live in the CALLER's flat fp32 buffers (one float per parameter element, any tensor order):
+ *   pn_trainer_set_param   where tensor `name` ("model0.layer1.0.conv1.weight", ...; the reference's state_dict keys) starts in
+ *                          both flat buffers (offset in floats; 16-byte aligned offsets recommended) and how many elements it has
+ *   pn_trainer_set_stat    device pointer of a BatchNorm running_mean / running_var tensor (updated in place every step)
+ *   pn_trainer_finalize    plans the step for batch B of H x W inputs (multiples of 8), allocates every activation / gradient
+ *                          tensor and descriptor; nothing is allocated afterwards (the step can be captured in a hipGraph)
+ *   pn_trainer_forward_backward   img [B,1,H,W], heat_gt [B,16,H/8,W/8], paf_gt [B,28,..], z_gt [B,15,..], fg_mask [B,15,..] f32 NCHW;
+ *                          writes the six loss terms (l1_paf, l1_heat, l1_z, l2_paf, l2_heat, l2_z) and every gradient
+ *                          (asynchronous on hip_stream); apply them with pn_sgd_nesterov. */
+typedef struct pn_trainer pn_trainer;
+pn_trainer *pn_trainer_create(pn_ctx *ctx);
+void pn_trainer_destroy(pn_trainer *t);
+int pn_trainer_set_param(pn_trainer *t, const char *name, size_t offset, size_t numel);
+int pn_trainer_set_stat(pn_trainer *t, const char *name, float *stat_dev);
+int pn_trainer_finalize(pn_trainer *t, float *flat_param_dev, float *flat_grad_dev, int B, int H, int W, float bn_momentum, float bn_eps);
+int pn_trainer_forward_backward(pn_trainer *t, const float *img_dev, const float *heat_gt_dev, const float *paf_gt_dev, const float *z_gt_dev,
+                                const float *fg_mask_dev, float *loss_terms_dev, void *hip_stream);
+/* split-bf16 MFMA FLOPs (3 x 2 MAC) of the convolutions one step runs on the matrix cores (forward + data gradient; the weight gradient has the forward's count) */
+double pn_trainer_conv_flops(pn_trainer *t);
+
 /* ---- Yolo-Pose+ decode ----------------------------------------------------------------------
  * Replaces parse_prior_pose (tpm/lib/utils/prior_pose_align.py:10-168, pred_vis=False), quirks
  * included (candidate order anchor-major; suppression loop over rows 1..n-2; inclusive

@@ -124,6 +124,13 @@ _SIGNATURES = {
     "pn_head_backward": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 5 + [_vp, _vp]),
     "pn_slice_copy": (_i, [_vp, _vp, _i, _vp] + [_i] * 5 + [_vp]),
     "pn_sgd_nesterov": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _i, _f, _vp]),
+    "pn_trainer_create": (_vp, [_vp]),
+    "pn_trainer_destroy": (None, [_vp]),
+    "pn_trainer_set_param": (_i, [_vp, C.c_char_p, _sz, _sz]),
+    "pn_trainer_set_stat": (_i, [_vp, C.c_char_p, _vp]),
+    "pn_trainer_finalize": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f]),
+    "pn_trainer_forward_backward": (_i, [_vp] * 8),
+    "pn_trainer_conv_flops": (_d, [_vp]),
     "pn_retrieve_depth": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "pn_nms_peaks": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "pn_parse_yolo": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _i, _i, _i, _f, _f, _f, _f, _i, C.POINTER(ParseCfg), _vp, _vp]),

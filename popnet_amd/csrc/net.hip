@@ -20,6 +20,7 @@
 #include <memory>
 #include <vector>
 #include "pn_internal.h"
+#include "conv_plan.h"
 #include "preproc_pixel.h"
 
 namespace {
@@ -162,20 +163,6 @@ int new_buf(pn_net *n, int H, int W, int C) {
     return (int)n->bufs.size() - 1;
 }
 
-int pick_pitch(int cols) {
-    const int classes[4] = {16, 32, 64, 120};
-    for (int c : classes)
-        if (cols <= c) return c;
-    return -1;
-}
-
-int pick_cfg(int cout) {
-    if (cout % 128 == 0) return PN_CFG_C128;
-    if (cout >= 64) return PN_CFG_C64;
-    if (cout <= 16) return PN_CFG_C16;
-    return PN_CFG_C32;
-}
-
 // Fold BN, permute/pad input channels, pack into MFMA A-fragment order (see conv_mfma.hip).
 int prepare_conv(pn_net *n, ConvSpec &cs) {
     pn_ctx *ctx = n->ctx;
@@ -267,50 +254,13 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
         return wsel[idx] ? v - hi : hi;
     };
 
-    cs.cfg = pick_cfg(cout);
-    {   // bf16 stride-1 layers run conv3_kernel (conv3_kernel.h) when the map splits into column strips (<= 30 wide: the
-        // halo row is 32 pixels) whose 4-row tiles fill >= 75 % of a wave group's 112 pixel slots
+    ConvGeom geo;                                  // which kernel, on what tiles: conv_plan.h (shared with the training engine)
+    geo.pt = cs.pt; geo.rpg = cs.rpg;
+    {
         const Buf &ib0 = n->bufs[cs.in_buf];
-        int segs = 0, wt = 0, rows = 0, rpg = 4;
-        double best = 0;
-        for (int sg = (ib0.W + 29) / 30; sg <= (ib0.W + 15) / 16; ++sg) {
-            const int w = (ib0.W + sg - 1) / sg;
-            for (int g : {4, 8}) {                       // rows per wave group kept in LDS (8: narrow maps only, 3x3 / 128-cout blocks)
-                if (g == 8 && !(w <= 14 && ks == 3 && cout > 64 && getenv("POPNET_CONV3_RPG8"))) continue;   // measured slower than the generic kernel on 14x14 maps (profiles/README.md v15)
-                const int r = std::min(std::min(ib0.H, g), 112 / w);
-                const double util = r * ((double)ib0.W / sg) / 112.0;
-                if (util > best + 1e-9) { best = util; segs = sg; wt = w; rows = r; rpg = g; }
-            }
-        }
-        if (n->prec == PN_PREC_BF16 && cs.stride == 1 && (ks == 3 || ks == 1) && best >= 0.75 && cout > 32 && !getenv("POPNET_NO_CONV3")) {
-            cs.kern = 3;
-            cs.wc = std::max(cout > 64 ? 4 : (cout > 32 ? 2 : 1), cs.wc_min);
-            const long tiles112 = (long)n->max_batch * ((ib0.H + rows - 1) / rows) * segs;   // strip tiles of one wave group
-            cs.wp = (cs.wc == 2 && rows == 4 && rpg == 4 && tiles112 * ((cout + 63) / 64) >= 1536) ? 2 : 1;   // big maps: 8-row tiles, 256 threads
-            cs.rpg = rpg;
-            if (cs.wp == 2 && ks == 3 && cs.cin_chunks == 1 && getenv("POPNET_CONV3_PT14") && atoi(getenv("POPNET_CONV3_PT14")) == 1) { cs.wp = 1; cs.pt = 14; cs.rpg = 8; }   // 8 rows per WAVE: half the weight bytes
-            if (const char *e = getenv("POPNET_CONV3_PT14"))          // =2: 128-cout blocks of 224-pixel wave tiles on every 28-column 3x3 level as well
-                if (atoi(e) == 2 && ks == 3 && cs.wc == 4 && cs.wp == 1 && rpg == 4 && rows == 4 && ib0.H >= 8) { cs.pt = 14; cs.rpg = 8; }
-            const int hr = rpg * cs.wp + ks - 1, ngw = (8 * (hr / 2) + cs.wc * cs.wp - 1) / (cs.wc * cs.wp);
-            // single halo image (4 waves / SIMD) beats the double-buffered variant (3 waves / SIMD) on every level
-            // of both networks (profiles/README.md, r01 v8); POPNET_CONV3_NBUF2=1 selects the latter for experiments
-            cs.nbuf = ((cs.cin_chunks > 1 || cs.nbuf_min == 2) && ks == 3 && ngw <= 18 && getenv("POPNET_CONV3_NBUF2")) ? 2 : 1;
-            cs.Wt = wt;
-            cs.R = std::min(ib0.H, rows * cs.wp * (cs.pt / 7));          // rows * Wt <= 112 (224) pixel slots per wave group
-            // conv4_kernel (both operands through LDS, 64-cout x 112-pixel wave tiles): the 3x3 layers with Cin >= 128 and
-            // >= 64 couts on 4-row strip tiles; a Cin = 64 conv joins only as the sibling of such a layer (one launch per level)
-            if (ks == 3 && cs.wp == 1 && cs.pt == 7 && cs.rpg == 4 && cout >= 64 && cs.k4_level)
-                cs.kern = 4;
-        }
+        pn_plan_conv_kernel(n->prec, n->max_batch, n->ctx->num_cus, ib0.H, ib0.W, cout, ks, cs.stride, cs.cin_chunks, cs.wc_min, cs.nbuf_min, cs.k4_level, geo);
     }
-    // Small maps on the generic kernel (YoloPoseNet's 14 x 14 levels: 2 tiles per frame): 128-cout blocks give fewer blocks than the chip
-    // has CUs (128 at B = 32) -- 64-cout x 128-pixel blocks double them.  POPNET_GENERIC_C64=0 keeps the 128-cout blocks.
-    if (cs.kern == 0 && n->prec == PN_PREC_BF16 && cs.cfg == PN_CFG_C128 && cs.stride == 1) {
-        const Buf &ib1 = n->bufs[cs.in_buf];
-        const long blocks128 = (long)n->max_batch * ((ib1.H * ib1.W + 111) / 112) * (cout / 128);
-        const char *e = getenv("POPNET_GENERIC_C64");
-        if (blocks128 < n->ctx->num_cus && !(e && atoi(e) == 0)) cs.cfg = PN_CFG_C64;
-    }
+    cs.cfg = geo.cfg; cs.kern = geo.kern; cs.wc = geo.wc; cs.wp = geo.wp; cs.nbuf = geo.nbuf; cs.pt = geo.pt; cs.rpg = geo.rpg; cs.Wt = geo.Wt; cs.R = geo.R;
     const int BC = cs.kern == 4 ? 128 : (cs.kern == 3 ? cs.wc * 32 : pn_cfg_couts(cs.cfg));
     const int cout_pad = (cout + BC - 1) / BC * BC;
     const int ctiles = cout_pad / 16;
@@ -358,30 +308,11 @@ int prepare_conv(pn_net *n, ConvSpec &cs) {
     // geometry
     const Buf &ib = n->bufs[cs.in_buf];
     const int Ho = (ib.H + 2 * (ks / 2) - ks) / cs.stride + 1, Wo = (ib.W + 2 * (ks / 2) - ks) / cs.stride + 1;
-    if (cs.kern == 3 || cs.kern == 4) {
-        cs.pitch = 32;
-        cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * (cs.embed3 ? 1 : KK);
-        if (cs.out_buf >= 0) {
-            const Buf &ob = n->bufs[cs.out_buf];
-            if (ob.H != Ho || ob.W != Wo) return pn_set_error(ctx, PN_ERR_INVALID, "%s: output buffer is %dx%d, conv gives %dx%d", cs.w.c_str(), ob.H, ob.W, Ho, Wo);
-        }
-        return PN_OK;
+    {
+        const char *why = "";
+        if (int rc = pn_plan_conv_tiles(n->prec, ib.H, ib.W, ks, cs.stride, geo, &why)) return pn_set_error(ctx, rc, "%s: %s", cs.w.c_str(), why);
+        cs.cfg = geo.cfg; cs.pitch = geo.pitch; cs.Wt = geo.Wt; cs.R = geo.R;
     }
-    if (cs.cfg == PN_CFG_C64 && ks == 3 && cs.stride == 1 && Wo >= 48 && (long)Ho * Wo >= 2048) cs.cfg = PN_CFG_C64W;   // wide maps: 224-pixel tiles
-    const int BP = pn_cfg_pixels(cs.cfg);
-    // a block owns R full rows when they fit its pixel tile, else one row cut into equal segments
-    const int wt_cap = std::min(BP, (120 - ks) / cs.stride + 1);     // widest segment the largest pitch class holds
-    const int segs = (Wo + wt_cap - 1) / wt_cap;
-    cs.Wt = (Wo + segs - 1) / segs;
-    cs.R = std::max(1, std::min(Ho, BP / cs.Wt));
-    {   // the register-prefetched staging path holds at most this many halo pixels
-        const int maxpx = pn_conv_stage_maxpx(n->prec, ks, cs.stride, pick_pitch((cs.Wt - 1) * cs.stride + ks), cs.cfg);
-        while (maxpx > 0 && cs.R > 1 && ((cs.R - 1) * cs.stride + ks) * ((cs.Wt - 1) * cs.stride + ks) > maxpx) --cs.R;
-        if (maxpx > 0 && ((cs.R - 1) * cs.stride + ks) * ((cs.Wt - 1) * cs.stride + ks) > maxpx)
-            return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo tile exceeds the staging capacity", cs.w.c_str());
-    }
-    cs.pitch = pick_pitch((cs.Wt - 1) * cs.stride + ks);
-    if (cs.pitch < 0) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "%s: halo width %d has no pitch class", cs.w.c_str(), (cs.Wt - 1) * cs.stride + ks);
     cs.flops = 2.0 * Ho * Wo * (double)cout * cin_ref * (cs.embed3 ? 1 : KK);
     if (cs.out_buf >= 0) {
         const Buf &ob = n->bufs[cs.out_buf];

@@ -1,0 +1,472 @@
+// Device kernels of the NHWC training engine (trainx.hip): everything between the convolutions of one training step of
+// rtpose_light3d on tensors stored as two bf16 planes [hi | lo] (value = hi + lo, 16 significant bits), channel-minor.
+//
+// Reference arithmetic being replaced (tpm/ = third_party_methods/):
+//   nn.BatchNorm2d in train mode + (residual) + ReLU / LeakyReLU(0.1)     tpm/lib/network/rtpose_light3d.py:48-72,222-246
+//   nn.AvgPool2d(3, 2, 1) and its gradient                                 tpm/lib/network/rtpose_light3d.py:152,158
+//   sigmoid range casts + rtpose_light3d_loss_fgweight and its gradient    tpm/lib/network/rtpose_light3d.py:335-337 ; tpm/lib/network/losses.py:65-106
+// Layout: a tensor is [B][H][W][2 * plane] bf16, plane a multiple of 64 (pad channels hold zeros and are never written);
+// every kernel moves 16-byte vectors of 8 channels.  No atomics: channel reductions write per-block partials that a finish
+// kernel adds in a fixed order (deterministic, like train.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tx {
+
+typedef __bf16 bf;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(4))) float f4;
+
+__device__ __forceinline__ void ld8(const bf *p, float (&v)[8]) {
+    const bf8 a = *reinterpret_cast<const bf8 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+// value = hi plane + lo plane
+__device__ __forceinline__ void ld8x(const bf *p, int split, float (&v)[8]) {
+    const bf8 a = *reinterpret_cast<const bf8 *>(p), b = *reinterpret_cast<const bf8 *>(p + split);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i] + (float)b[i];
+}
+__device__ __forceinline__ void st8x(bf *p, int split, const float (&v)[8]) {
+    bf8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bf hi = (bf)v[i];
+        h[i] = hi;
+        l[i] = (bf)(v[i] - (float)hi);
+    }
+    *reinterpret_cast<bf8 *>(p) = h;
+    *reinterpret_cast<bf8 *>(p + split) = l;
+}
+
+// ---- per-channel reductions over the pixels of a planes tensor --------------------------------------------------------------
+// MODE 0: s0 = sum x, s1 = sum x^2                       (BatchNorm batch statistics)
+// MODE 1: s0 = sum g, s1 = sum g * xhat                  (BatchNorm backward: g = dy * act'(y), xhat = (x - mean) * invstd)
+// MODE 2: s0 = sum x                                     (bias gradient)
+// Block = 256 threads = (C / 8 channel groups) x (256 / (C / 8) pixel lanes); block b owns pixels [b * ppb, (b + 1) * ppb).
+// partial[(block * C + c) * 2 + {0, 1}] (double).
+struct RedArgs {
+    const bf *x; int x_cs, x_split;          // MODE 0 / 2: the tensor; MODE 1: the convolution output (pre-BN)
+    const bf *dy; int dy_cs, dy_split;       // MODE 1: gradient w.r.t. the activation output
+    const bf *y; int y_cs;                   // MODE 1: activation output, hi plane (sign only) -- nullptr when act == 0
+    const float *mean, *invstd;              // MODE 1
+    int act;                                 // MODE 1: 0 none, 1 ReLU, 2 LeakyReLU(0.1)
+    int C; long npix; int ppb;
+    double *partial;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void reduce_kernel(RedArgs a) {
+    __shared__ float sh[2][256][9];
+    const int G = a.C >> 3, PL = 256 / G;
+    const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+    const long p0 = (long)blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.npix);
+    float s0[8], s1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s0[i] = s1[i] = 0.f;
+    float mu[8], is[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { mu[i] = a.mean[cg * 8 + i]; is[i] = a.invstd[cg * 8 + i]; }
+    }
+    if (pl < PL)
+        for (long p = p0 + pl; p < p1; p += PL) {
+            float x[8];
+            ld8x(a.x + p * a.x_cs + cg * 8, a.x_split, x);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s0[i] += x[i]; s1[i] += x[i] * x[i]; }
+            } else if (MODE == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s0[i] += x[i];
+            } else {
+                float g[8];
+                ld8x(a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
+                if (a.act) {
+                    float y[8];
+                    ld8(a.y + p * a.y_cs + cg * 8, y);
+                    const float neg = a.act == 2 ? 0.1f : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : g[i] * neg;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s0[i] += g[i]; s1[i] += g[i] * ((x[i] - mu[i]) * is[i]); }
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sh[0][threadIdx.x][i] = s0[i]; sh[1][threadIdx.x][i] = s1[i]; }
+    __syncthreads();
+    // thread (which, channel) adds the PL pixel lanes of its channel in order
+    for (int o = threadIdx.x; o < 2 * a.C; o += 256) {
+        const int which = o / a.C, c = o % a.C;
+        double s = 0.0;
+        for (int l = 0; l < PL; ++l) s += (double)sh[which][l * G + (c >> 3)][c & 7];
+        a.partial[((size_t)blockIdx.x * a.C + c) * 2 + which] = s;
+    }
+}
+
+// BatchNorm forward finish: partial sums -> mean / invstd / running statistics, and the per-channel affine of the apply pass.
+struct BnFinArgs {
+    const double *partial; int nblk, C; double n;       // n = pixels per channel
+    const float *gamma, *beta;
+    float *mean, *invstd, *scale, *shift;               // scale = gamma * invstd, shift = beta - mean * scale
+    float *running_mean, *running_var;                  // updated in place (momentum, unbiased variance) when given
+    float momentum, eps;
+};
+__global__ void bn_finish_kernel(BnFinArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < a.nblk; ++b) { s += a.partial[((size_t)b * a.C + c) * 2]; ss += a.partial[((size_t)b * a.C + c) * 2 + 1]; }
+    const double m = s / a.n;
+    double var = ss / a.n - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)a.eps);
+    a.mean[c] = (float)m;
+    a.invstd[c] = (float)is;
+    const double sc = (double)a.gamma[c] * is;
+    a.scale[c] = (float)sc;
+    a.shift[c] = (float)((double)a.beta[c] - m * sc);
+    if (a.running_mean) {
+        const double unb = a.n > 1.0 ? var * a.n / (a.n - 1.0) : var;
+        a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + (double)a.momentum * m);
+        a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + (double)a.momentum * unb);
+    }
+}
+
+// BatchNorm backward finish: dgamma = sum g xhat, dbeta = sum g (into the flat gradient), and the three per-channel constants
+// of dx = k1 (g - k2 - xhat k3)
+struct BnBwdFinArgs {
+    const double *partial; int nblk, C; double n;
+    const float *gamma, *invstd;
+    float *dgamma, *dbeta, *k1, *k2, *k3;
+};
+__global__ void bn_bwd_finish_kernel(BnBwdFinArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    double s = 0.0, sx = 0.0;
+    for (int b = 0; b < a.nblk; ++b) { s += a.partial[((size_t)b * a.C + c) * 2]; sx += a.partial[((size_t)b * a.C + c) * 2 + 1]; }
+    a.dbeta[c] = (float)s;
+    a.dgamma[c] = (float)sx;
+    a.k1[c] = a.gamma[c] * a.invstd[c];
+    a.k2[c] = (float)(s / a.n);
+    a.k3[c] = (float)(sx / a.n);
+}
+
+// channel sums -> out[c] (bias gradients), c < Cvalid
+__global__ void sum_finish_kernel(const double *__restrict__ partial, int nblk, int C, int Cvalid, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cvalid) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * C + c) * 2];
+    out[c] = (float)s;
+}
+
+// ---- BatchNorm apply: y = act(x * scale + shift [+ res]) ------------------------------------------------------------------
+struct BnApplyArgs {
+    const bf *x; int x_cs, x_split;
+    const bf *res; int res_cs, res_split;    // residual or nullptr
+    bf *y; int y_cs, y_split;
+    const float *scale, *shift;
+    int act, C; long npix;
+};
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+    const int G = a.C >> 3;
+    const long total = a.npix * G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / G;
+        const int cg = (int)(i - p * G);
+        float x[8], sc[8], sf[8];
+        ld8x(a.x + p * a.x_cs + cg * 8, a.x_split, x);
+        *reinterpret_cast<f4 *>(sc) = *reinterpret_cast<const f4 *>(a.scale + cg * 8);
+        *reinterpret_cast<f4 *>(sc + 4) = *reinterpret_cast<const f4 *>(a.scale + cg * 8 + 4);
+        *reinterpret_cast<f4 *>(sf) = *reinterpret_cast<const f4 *>(a.shift + cg * 8);
+        *reinterpret_cast<f4 *>(sf + 4) = *reinterpret_cast<const f4 *>(a.shift + cg * 8 + 4);
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = x[k] * sc[k] + sf[k];
+        if (a.res) {
+            float r[8];
+            ld8x(a.res + p * a.res_cs + cg * 8, a.res_split, r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] += r[k];
+        }
+        if (a.act == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = y[k] > 0.f ? y[k] : 0.f;
+        } else if (a.act == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = y[k] > 0.f ? y[k] : y[k] * 0.1f;
+        }
+        st8x(a.y + p * a.y_cs + cg * 8, a.y_split, y);
+    }
+}
+
+// ---- BatchNorm backward apply: g = dy act'(y); dx = k1 (g - k2 - xhat k3); dres = g ------------------------------------------
+struct BnBwdApplyArgs {
+    const bf *x; int x_cs, x_split;
+    const bf *dy; int dy_cs, dy_split;
+    const bf *y; int y_cs;
+    const float *mean, *invstd, *k1, *k2, *k3;
+    bf *dx; int dx_cs, dx_split;
+    bf *dres; int dres_cs, dres_split;       // gradient of the residual input (= g) or nullptr
+    int act, C; long npix;
+};
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs a) {
+    const int G = a.C >> 3;
+    const long total = a.npix * G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / G;
+        const int cg = (int)(i - p * G);
+        float x[8], g[8];
+        ld8x(a.x + p * a.x_cs + cg * 8, a.x_split, x);
+        ld8x(a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
+        if (a.act) {
+            float y[8];
+            ld8(a.y + p * a.y_cs + cg * 8, y);
+            const float neg = a.act == 2 ? 0.1f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = y[k] > 0.f ? g[k] : g[k] * neg;
+        }
+        float d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cg * 8 + k;
+            const float xh = (x[k] - a.mean[c]) * a.invstd[c];
+            d[k] = a.k1[c] * (g[k] - a.k2[c] - xh * a.k3[c]);
+        }
+        st8x(a.dx + p * a.dx_cs + cg * 8, a.dx_split, d);
+        if (a.dres) st8x(a.dres + p * a.dres_cs + cg * 8, a.dres_split, g);
+    }
+}
+
+// ---- AvgPool2d(3, 2, 1) backward (count_include_pad): dx[iy, ix] = sum of dy over the windows that hold it / 9 -----------------
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf *__restrict__ dy, int dy_cs, int dy_split, bf *__restrict__ dx, int dx_cs, int dx_split,
+                                                          int B, int H, int W, int Ho, int Wo, int C) {
+    const int G = C >> 3;
+    const long total = (long)B * H * W * G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % G);
+        long p = i / G;
+        const int ix = (int)(p % W);
+        p /= W;
+        const int iy = (int)(p % H), b = (int)(p / H);
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = 0.f;
+        for (int oy = iy >> 1; oy <= ((iy + 1) >> 1); ++oy)
+            for (int ox = ix >> 1; ox <= ((ix + 1) >> 1); ++ox)
+                if (oy < Ho && ox < Wo) {
+                    float v[8];
+                    ld8x(dy + ((long)(b * Ho + oy) * Wo + ox) * dy_cs + cg * 8, dy_split, v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s[k] += v[k];
+                }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = s[k] / 9.f;
+        st8x(dx + ((long)(b * H + iy) * W + ix) * dx_cs + cg * 8, dx_split, s);
+    }
+}
+
+// ---- sum of up to four planes tensors (gradients meeting at a fan-out) ----------------------------------------------------------
+struct AddArgs {
+    const bf *in[4]; int cs[4], split[4]; int n;
+    bf *out; int out_cs, out_split;
+    int C; long npix;
+};
+__global__ __launch_bounds__(256) void add_kernel(AddArgs a) {
+    const int G = a.C >> 3;
+    const long total = a.npix * G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / G;
+        const int cg = (int)(i - p * G);
+        float s[8];
+        ld8x(a.in[0] + p * a.cs[0] + cg * 8, a.split[0], s);
+        for (int k = 1; k < a.n; ++k) {
+            float v[8];
+            ld8x(a.in[k] + p * a.cs[k] + cg * 8, a.split[k], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+        st8x(a.out + p * a.out_cs + cg * 8, a.out_split, s);
+    }
+}
+
+// ---- heads: loss and its gradient from the activated output ------------------------------------------------------------------------
+// out [B][C][HW] f32 = s (kind 0) or (s - 0.5) * 4 (kind 1), s = sigmoid(v), as the convolution epilogue wrote it (PN_ACT_SIG / PN_ACT_SIG_PM2).
+//   loss partial = sum w (out - t)^2,  w = 0.1 + 0.9 fg (fg != nullptr) else 1                     losses.py:65-90
+//   dv = (2 w (out - t) / numel + dextra) * (kind ? 4 : 1) * s (1 - s)                          -> planes [B][HW][2 * dv_plane], channels >= C stay zero
+// dextra: channel slice of a planes tensor (the gradient that reaches a stage-1 head through the stage-2 input) or nullptr.
+struct HeadArgs {
+    const float *out, *target, *fg;
+    const bf *dextra; int de_cs, de_split;
+    bf *dv; int dv_cs, dv_split;
+    int kind, C, HW; long total; float inv_numel;
+    double *partial;
+};
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+    __shared__ double sh[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    double e = 0.0;
+    if (i < a.total) {
+        const float o = a.out[i];
+        const float s = a.kind ? o * 0.25f + 0.5f : o;
+        const long n = i / ((long)a.C * a.HW), rem = i - n * (long)a.C * a.HW;
+        const int c = (int)(rem / a.HW), p = (int)(rem - (long)c * a.HW);
+        const float d = o - a.target[i];
+        const float w = a.fg ? 0.1f + a.fg[i] * 0.9f : 1.f;
+        e = (double)(d * d * w);
+        float g = 2.f * d * w * a.inv_numel;
+        const long pix = n * a.HW + p;
+        if (a.dextra) g += (float)a.dextra[pix * a.de_cs + c] + (float)a.dextra[pix * a.de_cs + c + a.de_split];
+        if (a.kind) g *= 4.f;
+        const float dv = g * (1.f - s) * s;
+        const bf hi = (bf)dv;
+        a.dv[pix * a.dv_cs + c] = hi;
+        a.dv[pix * a.dv_cs + c + a.dv_split] = (bf)(dv - (float)hi);
+    }
+    // block sum (double): wave shuffles, then four partials through LDS
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void loss_finish_kernel(const double *__restrict__ partial, int nblocks, double numel, float *__restrict__ loss) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (float)((sh[0] + sh[1] + sh[2] + sh[3]) / numel);
+}
+
+// ---- layout hand-over at the stem (the 7x7 Cin = 1 convolution keeps train.hip's NCHW f32 kernels) and for the legacy weight gradient ----
+// NCHW f32 [B][C][HW] -> planes [B][HW][2 * plane]: 64-pixel x 64-channel tiles through LDS (coalesced on both sides)
+__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__restrict__ in, bf *__restrict__ out, int C, int HW, int out_cs, int out_split) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+        const int c = k >> 6, p = k & 63;
+        tile[c][p] = (c0 + c < C && p0 + p < HW) ? in[((size_t)b * C + c0 + c) * HW + p0 + p] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 64 * 8; k += 256) {
+        const int p = k >> 3, cg = k & 7;
+        if (p0 + p >= HW || c0 + cg * 8 >= C) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[cg * 8 + j][p];
+        st8x(out + ((size_t)b * HW + p0 + p) * out_cs + c0 + cg * 8, out_split, v);
+    }
+}
+// planes -> NCHW f32 [B][Cout][HW]; channel c of the output is channel map[c] of the planes tensor (map == nullptr: c)
+__global__ __launch_bounds__(256) void planes_to_nchw_kernel(const bf *__restrict__ in, int in_cs, int in_split, float *__restrict__ out, int Cout, int HW,
+                                                             const int *__restrict__ map) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    if (!map) {
+        for (int k = threadIdx.x; k < 64 * 8; k += 256) {
+            const int p = k >> 3, cg = k & 7;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (p0 + p < HW && c0 + cg * 8 < Cout) ld8x(in + ((size_t)b * HW + p0 + p) * in_cs + c0 + cg * 8, in_split, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[cg * 8 + j][p] = v[j];
+        }
+    } else {
+        for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+            const int p = k >> 6, c = k & 63;
+            float v = 0.f;
+            if (p0 + p < HW && c0 + c < Cout) {
+                const bf *q = in + ((size_t)b * HW + p0 + p) * in_cs + map[c0 + c];
+                v = (float)q[0] + (float)q[in_split];
+            }
+            tile[c][p] = v;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+        const int c = k >> 6, p = k & 63;
+        if (c0 + c < Cout && p0 + p < HW) out[((size_t)b * Cout + c0 + c) * HW + p0 + p] = tile[c][p];
+    }
+}
+
+// ---- weight packs: fp32 parameters -> split-bf16 MFMA fragments, every convolution of the step in ONE launch ----------------------
+// A pack is what net.hip::prepare_conv builds on the host for an inference net, rebuilt on the device from the live parameters:
+//   rows x k, k = three plane passes [x_hi | x_lo | x_hi] against [W_hi | W_hi | W_lo]; layouts of conv3_kernel / conv_mfma_kernel
+//   ([cout tile][k-step][lane][8]) and conv4_kernel ([cout block][k-step + 3 spare][8 tiles][lane][8]).
+// transpose = 1 is the data-gradient pack: rows = input channels, k = output channels, taps rotated by 180 degrees.
+struct PackDesc {
+    const float *w; bf *dst;
+    int Cout, Cin, ks;
+    int transpose, conv4, CT;
+    int rows_valid;          // rows that exist (cout, or the input plane for a transposed pack)
+    int kplane;              // channels of one plane of the k side
+    int ksteps;              // 3 * kplane / 64 * ks * ks * 2
+    const int *row_map;      // transposed pack: row -> reference input channel (nullptr = identity); -1 = zero row
+    const int *k_map;        // forward pack: plane channel -> reference input channel (nullptr = identity); -1 = zero column
+    unsigned first_group, ngroups;      // 16-byte groups of this pack in the launch
+};
+__device__ __forceinline__ int row_channel(int tile, int row, int CT) { return (tile / CT) * CT * 16 + 4 * CT * (row >> 2) + 4 * (tile % CT) + (row & 3); }
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc *__restrict__ tab, int n, unsigned total_groups) {
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= total_groups) return;
+    int lo = 0, hi = n - 1;                         // the pack that holds this group
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_group <= gid) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = tab[lo];
+    const unsigned g = gid - d.first_group;
+    const int KK = d.ks * d.ks;
+    const int lane = (int)(g & 63u);
+    int row, kstep;
+    if (d.conv4) {
+        const unsigned t = (g >> 6) & 7u, rest = g >> 9;
+        kstep = (int)(rest % (unsigned)(d.ksteps + 3));
+        const int cbk = (int)(rest / (unsigned)(d.ksteps + 3));
+        if (kstep >= d.ksteps) return;              // spare k-steps stay zero
+        row = cbk * 128 + row_channel((int)t, lane & 15, 4);
+    } else {
+        const unsigned frag = g >> 6;
+        kstep = (int)(frag % (unsigned)d.ksteps);
+        row = row_channel((int)(frag / (unsigned)d.ksteps), lane & 15, d.CT);
+    }
+    const int tap = kstep % KK, hs = kstep / KK;
+    const int k0 = hs * 32 + 8 * (lane >> 4);
+    bf8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kidx = k0 + j, pl = kidx / d.kplane, i = kidx - pl * d.kplane;
+        int co, ci, tw;
+        if (!d.transpose) {
+            co = row < d.rows_valid ? row : -1;
+            ci = d.k_map ? d.k_map[i] : (i < d.Cin ? i : -1);
+            tw = tap;
+        } else {
+            ci = row < d.rows_valid ? (d.row_map ? d.row_map[row] : (row < d.Cin ? row : -1)) : -1;
+            co = i < d.Cout ? i : -1;
+            tw = KK - 1 - tap;
+        }
+        float v = 0.f;
+        if (co >= 0 && ci >= 0) v = d.w[((size_t)co * d.Cin + ci) * KK + tw];
+        const bf h = (bf)v;
+        o[j] = pl == 2 ? (bf)(v - (float)h) : h;
+    }
+    *reinterpret_cast<bf8 *>(d.dst + (size_t)g * 8) = o;
+}
+
+// padded copies of the convolution biases (the epilogues read whole cout tiles)
+struct BiasDesc { const float *src; float *dst; int n, npad; };
+__global__ void bias_kernel(const BiasDesc *__restrict__ tab, int n) {
+    const BiasDesc d = tab[blockIdx.x];
+    (void)n;
+    for (int i = threadIdx.x; i < d.npad; i += blockDim.x) d.dst[i] = i < d.n ? d.src[i] : 0.f;
+}
+
+}  // namespace tx

@@ -1,0 +1,239 @@
+// Weight gradient of a 3x3 / 1x1 stride-1 "same" convolution on NHWC [hi | lo] bf16 planes: a pixel-K GEMM on the matrix cores.
+//
+//   dW[co][ci][ky][kx] = sum over (n, y, x) of dy[n, y, x, co] * x[n, y + ky - pad, x + kx - pad, ci]      (autograd of nn.Conv2d:
+//   tpm/lib/network/rtpose_light3d.py:24-34,222-246 under tpm/train_rtpose_light3d_kdh3d_mpaug.py:160-180 (CR))
+// with every product taken as dy_hi x_hi + dy_lo x_hi + dy_hi x_lo (split-bf16, fp32 accumulate).
+//
+// MFMA view: D[co][ci] += A[co][k] B[k][ci] with k = PIXEL.  Both operands are channel-minor in memory, so both fragments are
+// "k-strided": they are read from LDS with ds_read_b64_tr_b16 (gfx950's transposing read: a 4-pixel x 16-channel block arrives
+// pixel-minor), the one instruction that makes an NHWC weight gradient cheap -- no second (pixel-minor) copy of any tensor exists.
+//   * block = 4 waves = 64 couts x 64 cins x all taps; wave = 32 x 32 x KS*KS accumulator tiles (144 VGPRs for 3x3);
+//   * a k-chunk is one ROW SEGMENT of <= 30 pixels (32 slots, the surplus slots hold dy = 0): the dy fragment of a row is read once and
+//     multiplied with the nine shifted x fragments (tap = an immediate LDS offset: the halo image is [row][plane][32 px][128 B]);
+//   * images are filled by LDS-DMA (global_load_lds_dwordx4, no staging registers), 16-byte slots XOR-swizzled by the pixel so that the
+//     eight pixels a half-wave's transposed read touches cover all 64 banks once -- for every tap shift;
+//   * k -> pixel map of a fragment: lane group g, read j, row q  <->  pixel 16 j + 4 g + q (any map works as long as A and B share it;
+//     this one keeps a half-wave on eight CONSECUTIVE pixels);
+//   * deterministic split-K: block s of a tile pair sums its strips into partial[s], wgrad_reduce_kernel adds the slices in order and
+//     scatters to the reference's [Cout][Cin][k][k] layout (undoing this engine's channel order of the stage-2 input).
+#pragma once
+#include <functional>
+#include <vector>
+#include "pn_internal.h"
+#include "trainx_kernels.h"
+
+namespace tx {
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+
+struct WgArgs {
+    const bf *x; int x_cs, x_split; unsigned x_zero;        // input tensor, byte offset of its zero page
+    const bf *dy; int dy_cs, dy_split; unsigned dy_zero;    // output gradient
+    int B, H, W;
+    int Wt, tiles_x, strips_per_img, nstrips, strips_per_block;
+    int ncit;                                               // 64-channel tiles on the cin side (blockIdx.y = cot * ncit + cit)
+    int co_pad, ci_pad;
+    float *partial;                                         // [split][tap][co_pad][ci_pad]
+};
+
+__device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int KS, int R>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
+    typedef __attribute__((address_space(3))) bf4 lds4;
+    constexpr int KK = KS * KS, PAD = KS / 2, HR = R + KS - 1;
+    constexpr int ROWB = 2 * 32 * 128;                    // bytes of one image row: 2 planes x 32 pixel slots x 64 channels
+    constexpr int XIMG = HR * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [x halo image][dy image]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;              // cout half, cin half of the 64 x 64 block tile
+    const int cot = blockIdx.y / a.ncit, cit = blockIdx.y - cot * a.ncit;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int pxl = 4 * g + q;
+
+    // transposed-read addresses (bytes): lane 4q + p of group g supplies row (= pixel) q, channels 4p .. 4p + 3 of the 16-channel window
+    int addrA[2], addrB[KS][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int win = wm * 2 + mt, swz = (pxl >> 1) & 3;
+        addrA[mt] = XIMG + pxl * 128 + ((((win ^ swz) << 1) | (p >> 1)) << 4) + ((p & 1) << 3);
+    }
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int win = wn * 2 + nt, hp = pxl + kx, swz = (hp >> 1) & 3;
+            addrB[kx][nt] = hp * 128 + ((((win ^ swz) << 1) | (p >> 1)) << 4) + ((p & 1) << 3);
+        }
+
+    f4 acc[2][2][KK];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int tp = 0; tp < KK; ++tp) acc[mt][nt][tp] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA lane roles: one instruction = 8 pixels x 8 slots of 16 B (one plane); slot sp of pixel px holds logical slot ((sp >> 1) ^ ((px >> 1) & 3)) << 1 | (sp & 1)
+    const int dpx = lane >> 3, dsp = lane & 7;
+    const int s0 = blockIdx.x * a.strips_per_block, s1 = min(s0 + a.strips_per_block, a.nstrips);
+    for (int sid = s0; sid < s1; ++sid) {
+        const int b = sid / a.strips_per_img, rem = sid - b * a.strips_per_img;
+        const int ty = rem / a.tiles_x, tx_ = rem - ty * a.tiles_x;
+        const int oy0 = ty * R, ox0 = tx_ * a.Wt;
+        const int Wc = min(a.Wt, a.W - ox0);
+        __syncthreads();                                   // every wave has finished reading the previous strip's images
+        // x halo image: HR rows x 2 planes, dy image: R rows x 2 planes; each (row, plane) is four 8-pixel pieces: wave w fetches piece w of every one
+        {
+            const int pg = wave, px = pg * 8 + dpx;
+            const int lslot = (((dsp >> 1) ^ ((px >> 1) & 3)) << 1) | (dsp & 1);
+#pragma unroll
+            for (int i = 0; i < HR * 2; ++i) {
+                const int row = i >> 1, pl = i & 1;
+                const int iy = oy0 - PAD + row, ix = ox0 - PAD + px;
+                const bool inb = px < Wc + 2 * PAD && (unsigned)ix < (unsigned)a.W && (unsigned)iy < (unsigned)a.H;
+                const unsigned off = inb ? (unsigned)((((size_t)(b * a.H + iy) * a.W + ix) * a.x_cs + pl * a.x_split + ci0 + lslot * 8) * 2) : a.x_zero;
+                glds16(a.x, off, (unsigned)(i * 4096 + pg * 1024));
+            }
+#pragma unroll
+            for (int i = 0; i < R * 2; ++i) {
+                const int row = i >> 1, pl = i & 1;
+                const int iy = oy0 + row, ix = ox0 + px;
+                const bool inb = px < Wc && iy < a.H;
+                const unsigned off = inb ? (unsigned)((((size_t)(b * a.H + iy) * a.W + ix) * a.dy_cs + pl * a.dy_split + co0 + lslot * 8) * 2) : a.dy_zero;
+                glds16(a.dy, off, (unsigned)(XIMG + i * 4096 + pg * 1024));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (oy0 + r >= a.H) break;                     // wave-uniform: rows below the map hold dy = 0
+            bf8 A[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const bf4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrA[mt] + r * ROWB + pl * 4096));
+                    const bf4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrA[mt] + r * ROWB + pl * 4096 + 2048));
+                    A[mt][pl] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    bf8 Bf[2][2];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+                            const bf4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + (r + ky) * ROWB + pl * 4096));
+                            const bf4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + (r + ky) * ROWB + pl * 4096 + 2048));
+                            Bf[nt][pl] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                    const int tp = ky * KS + kx;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][0], Bf[nt][0], acc[mt][nt][tp], 0, 0, 0);
+                            acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][1], Bf[nt][0], acc[mt][nt][tp], 0, 0, 0);
+                            acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][0], Bf[nt][1], acc[mt][nt][tp], 0, 0, 0);
+                        }
+                }
+        }
+    }
+    // partial[split][tap][co][ci]: a lane's 16 neighbours write 64 contiguous bytes
+    float *part = a.partial + (size_t)blockIdx.x * KK * a.co_pad * a.ci_pad;
+#pragma unroll
+    for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + wm * 32 + mt * 16 + 4 * g + i, ci = ci0 + wn * 32 + nt * 16 + (lane & 15);
+                    part[((size_t)tp * a.co_pad + co) * a.ci_pad + ci] = acc[mt][nt][tp][i];
+                }
+}
+
+// dw[co][ref ci][tap] = sum over the split slices, in order; k_map: this engine's input channel -> the reference's (nullptr = identity)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S, int KK, int co_pad, int ci_pad, int Cout, int Cin, const int *__restrict__ k_map,
+                                                            float *__restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= co_pad * ci_pad) return;
+    const int co = idx / ci_pad, ci = idx - co * ci_pad;
+    if (co >= Cout) return;
+    const int ref = k_map ? k_map[ci] : (ci < Cin ? ci : -1);
+    if (ref < 0) return;
+    const float *p = partial + idx;
+    const size_t tap_stride = (size_t)co_pad * ci_pad, split_stride = tap_stride * KK;
+    for (int tp = 0; tp < KK; ++tp) {
+        float s = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= S; sp += 4) {                     // four slices in flight, added in order
+            const float v0 = p[(size_t)sp * split_stride + tp * tap_stride], v1 = p[(size_t)(sp + 1) * split_stride + tp * tap_stride];
+            const float v2 = p[(size_t)(sp + 2) * split_stride + tp * tap_stride], v3 = p[(size_t)(sp + 3) * split_stride + tp * tap_stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; sp < S; ++sp) s += p[(size_t)sp * split_stride + tp * tap_stride];
+        dw[((size_t)co * Cin + ref) * KK + tp] = s;
+    }
+}
+
+// Plans the weight gradient of one layer and appends its two launches to `ops`.  *partial_floats grows to what the layer needs; the
+// buffer itself (*partial) is allocated by the caller after every layer has been planned (the kernels read the pointer at launch time).
+inline int plan_wgrad(pn_ctx *ctx, int B, int H, int W, const bf *x, int x_plane, const bf *dy, int dy_plane, int Cin, int Cout, int ks, const int *k_map, float *dw,
+                      float *const *partial, size_t *partial_floats, std::vector<std::function<int(hipStream_t)>> &ops) {
+    if (ks != 1 && ks != 3) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "weight gradient on planes: kernel size %d not built", ks);
+    const int R = ks == 3 ? 3 : 4, KK = ks * ks, pad = ks / 2;
+    const int seg_max = 32 - 2 * pad;                      // a halo row holds 32 pixels
+    WgArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.x_cs = 2 * x_plane; a.x_split = x_plane; a.x_zero = (unsigned)((size_t)B * H * W * 2 * x_plane * 2);
+    a.dy = dy; a.dy_cs = 2 * dy_plane; a.dy_split = dy_plane; a.dy_zero = (unsigned)((size_t)B * H * W * 2 * dy_plane * 2);
+    a.B = B; a.H = H; a.W = W;
+    a.tiles_x = (W + seg_max - 1) / seg_max;
+    a.Wt = (W + a.tiles_x - 1) / a.tiles_x;
+    a.strips_per_img = ((H + R - 1) / R) * a.tiles_x;
+    a.nstrips = B * a.strips_per_img;
+    const int ci_my = k_map ? x_plane : Cin;               // channels of x that carry weights (the stage-2 input: the whole plane, re-ordered)
+    const int ncot = (Cout + 63) / 64;
+    a.ncit = (ci_my + 63) / 64;
+    a.co_pad = ncot * 64; a.ci_pad = a.ncit * 64;
+    if (a.co_pad > dy_plane || a.ci_pad > x_plane) return pn_set_error(ctx, PN_ERR_INVALID, "weight gradient on planes: channel tiles exceed the planes");
+    const int pairs = ncot * a.ncit;
+    int S = std::max(1, std::min(a.nstrips, (2 * ctx->num_cus + pairs - 1) / pairs));
+    a.strips_per_block = (a.nstrips + S - 1) / S;
+    S = (a.nstrips + a.strips_per_block - 1) / a.strips_per_block;
+    *partial_floats = std::max(*partial_floats, (size_t)S * KK * a.co_pad * a.ci_pad);
+    const size_t lds = (size_t)((R + ks - 1) + R) * 8192;
+    const WgArgs a0 = a;
+    ops.push_back([=](hipStream_t s) {
+        WgArgs a = a0;
+        a.partial = *partial;                              // the host reads the pointer when the step launches (the buffer exists by then)
+        if (ks == 3) {
+            static PnLdsAttr attr;
+            if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(wgrad_kernel<3, 3>), lds)) return rc;
+            hipLaunchKernelGGL((wgrad_kernel<3, 3>), dim3(S, pairs), dim3(256), lds, s, a);
+        } else {
+            static PnLdsAttr attr;
+            if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(wgrad_kernel<1, 4>), lds)) return rc;
+            hipLaunchKernelGGL((wgrad_kernel<1, 4>), dim3(S, pairs), dim3(256), lds, s, a);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.co_pad * a.ci_pad + 255) / 256), dim3(256), 0, s, (const float *)a.partial, S, KK, a.co_pad, a.ci_pad, Cout, Cin, k_map, dw);
+        PN_HIP_CHECK(ctx, hipGetLastError());
+        return (int)PN_OK;
+    });
+    return PN_OK;
+}
+
+}  // namespace tx

@@ -39,10 +39,15 @@ class TrainEngine:
             raise _lib.PopnetError("popnet_amd.train: a ROCm device is required -- the HIP path has no CPU fallback")
         self.L = _lib.lib()
         self.ctx = _lib.Context(self.device.index or 0)            # private: its own scratch and precision switch
-        if precision not in ("fp32", "bf16x3"):
-            raise ValueError("precision must be 'fp32' or 'bf16x3', got %r" % (precision,))
+        if precision not in ("fp32", "bf16x3", "bf16x3-nchw"):
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16x3-nchw', got %r" % (precision,))
         self.precision = precision
-        self.ctx.check(self.L.pn_train_set_precision(self.ctx.handle, _lib.PN_PREC_BF16X3 if precision == "bf16x3" else 0), "pn_train_set_precision")
+        # "bf16x3" (round 6): the whole step on NHWC [hi | lo] bf16 planes -- csrc/trainx.hip, one C++ object per batch shape, forward and
+        # data-gradient convolutions on the inference kernels, pixel-K MFMA weight gradient.  "bf16x3-nchw": the round 2-5 form (fp32 NCHW
+        # tensors, only the 3x3 convolutions split) -- kept for the autograd wrappers' kernels and as a cross-check.
+        self.planes = precision == "bf16x3"
+        self._trainers = {}
+        self.ctx.check(self.L.pn_train_set_precision(self.ctx.handle, _lib.PN_PREC_BF16X3 if precision != "fp32" else 0), "pn_train_set_precision")
         # packed conv weights cached in the (private) context and refreshed by ONE launch at the start of every step (forward_backward)
         self.ctx.check(self.L.pn_train_pack_cache(self.ctx.handle, 1), "pn_train_pack_cache")
         self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
@@ -62,6 +67,7 @@ class TrainEngine:
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.p, self.g = {}, {}
+        self._offsets = dict(zip(names, zip(offs, sizes)))
         for k, n, off in zip(names, sizes, offs):
             self.p[k] = self.flat_p[off:off + n].view(sd[k].shape)
             self.g[k] = self.flat_g[off:off + n].view(sd[k].shape)
@@ -79,6 +85,30 @@ class TrainEngine:
         """From a popnet_amd.network.rtpose_light3d.rtpose_light3d (or the reference's own module): its state_dict is copied;
         module.load_state_dict(engine.state_dict()) hands the trained weights back to the inference path."""
         return cls(module.state_dict(), **kw)
+
+    def _trainer(self, N, H, W):
+        """The pn_trainer of this batch shape (plans the step and allocates every activation / gradient tensor once; a step at another
+        shape gets its own, so a hipGraph captured for the first keeps pointing at live buffers)."""
+        tr = self._trainers.get((N, H, W))
+        if tr is None:
+            tr = self.L.pn_trainer_create(self.ctx.handle)
+            if not tr:
+                raise _lib.PopnetError("pn_trainer_create failed")
+            for k, (off, n) in self._offsets.items():
+                self._check(self.L.pn_trainer_set_param(tr, k.encode(), off, n), "pn_trainer_set_param")
+            for k, v in self.stats.items():
+                self._check(self.L.pn_trainer_set_stat(tr, k.encode(), self._ptr(v)), "pn_trainer_set_stat")
+            self._check(self.L.pn_trainer_finalize(tr, self._ptr(self.flat_p), self._ptr(self.flat_g), N, H, W, BN_MOMENTUM, BN_EPS), "pn_trainer_finalize")
+            self._trainers[(N, H, W)] = tr
+        return tr
+
+    def __del__(self):
+        try:
+            for tr in getattr(self, "_trainers", {}).values():
+                self.L.pn_trainer_destroy(tr)
+            self._trainers = {}
+        except Exception:
+            pass
 
     # ---- plumbing ----
     def _s(self):
@@ -228,6 +258,12 @@ class TrainEngine:
             raise _lib.PopnetError("popnet_amd.train: fg_mask must be [%d, 15, %d, %d]" % (N, h, w))
         self.A = {}
         L, ctx, s = self.L, self.ctx.handle, self._s()
+        if self.planes:
+            self._check(L.pn_trainer_forward_backward(self._trainer(N, H, W), self._ptr(img), self._ptr(heat_gt), self._ptr(paf_gt), self._ptr(z_gt), self._ptr(fg_mask),
+                                                      self._ptr(self.loss_terms), s), "pn_trainer_forward_backward")
+            for k in self.tracked:
+                self.tracked[k] += 1
+            return self.loss_terms
         self._check(L.pn_train_pack_refresh(ctx, s), "pn_train_pack_refresh")       # every cached weight pack, one launch (whatever changed the weights)
         # forward (rtpose_light3d.py:206-219, 328-354)
         a = self._bn("model0.bn1", self._conv("model0.conv1", img, 7, 2, 3), ACT_RELU)
