@@ -340,7 +340,7 @@ void op_bn_fwd(pn_trainer *t, int bn, int x, int res, int y, int act) {
         f.partial = t->partial; f.nblk = nblk; f.C = C; f.n = (double)npix; f.gamma = b.gamma; f.beta = b.beta;
         f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift; f.running_mean = b.rm; f.running_var = b.rv;
         f.momentum = t->momentum; f.eps = t->eps;
-        hipLaunchKernelGGL(tx::bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, f);
+        hipLaunchKernelGGL(tx::bn_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, f);
         tx::BnApplyArgs a;
         memset(&a, 0, sizeof a);
         a.x = X.p; a.x_cs = X.cs(); a.x_split = X.plane;
@@ -370,7 +370,7 @@ void op_bn_bwd(pn_trainer *t, int bn, int x, int dy, int y, int dx, int dres, in
         tx::BnBwdFinArgs f;
         f.partial = t->partial; f.nblk = nblk; f.C = C; f.n = (double)npix; f.gamma = b.gamma; f.invstd = b.invstd;
         f.dgamma = b.dgamma; f.dbeta = b.dbeta; f.k1 = b.k1; f.k2 = b.k2; f.k3 = b.k3;
-        hipLaunchKernelGGL(tx::bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, f);
+        hipLaunchKernelGGL(tx::bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, f);
         tx::BnBwdApplyArgs a;
         memset(&a, 0, sizeof a);
         a.x = X.p; a.x_cs = X.cs(); a.x_split = X.plane; a.dy = DY.p; a.dy_cs = DY.cs(); a.dy_split = DY.plane;
@@ -398,7 +398,7 @@ void op_dbias(pn_trainer *t, int l, int dy) {
         memset(&r, 0, sizeof r);
         r.x = DY.p; r.x_cs = DY.cs(); r.x_split = DY.plane; r.C = C; r.npix = npix; r.ppb = ppb; r.partial = t->partial;
         hipLaunchKernelGGL(tx::reduce_kernel<2>, dim3(nblk), dim3(256), 0, s, r);
-        hipLaunchKernelGGL(tx::sum_finish_kernel, dim3((L.cout + 63) / 64), dim3(64), 0, s, (const double *)t->partial, nblk, C, L.cout, L.db);
+        hipLaunchKernelGGL(tx::sum_finish_kernel, dim3((L.cout + 3) / 4), dim3(256), 0, s, (const double *)t->partial, nblk, C, L.cout, L.db);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });

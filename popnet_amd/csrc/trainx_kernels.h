@@ -115,11 +115,19 @@ struct BnFinArgs {
     float *running_mean, *running_var;                  // updated in place (momentum, unbiased variance) when given
     float momentum, eps;
 };
-__global__ void bn_finish_kernel(BnFinArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per channel: lanes stride over the partial blocks (independent loads in flight), then a fixed-order butterfly -- deterministic
+__device__ __forceinline__ void wave_sum2(const double *__restrict__ partial, int nblk, int C, int c, double &s0, double &s1) {
+    const int lane = threadIdx.x & 63;
+    s0 = 0.0; s1 = 0.0;
+    for (int b = lane; b < nblk; b += 64) { s0 += partial[((size_t)b * C + c) * 2]; s1 += partial[((size_t)b * C + c) * 2 + 1]; }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
+}
+__global__ __launch_bounds__(256) void bn_finish_kernel(BnFinArgs a) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < a.nblk; ++b) { s += a.partial[((size_t)b * a.C + c) * 2]; ss += a.partial[((size_t)b * a.C + c) * 2 + 1]; }
+    double s, ss;
+    wave_sum2(a.partial, a.nblk, a.C, c, s, ss);
+    if (threadIdx.x & 63) return;
     const double m = s / a.n;
     double var = ss / a.n - m * m;
     if (var < 0.0) var = 0.0;
@@ -143,11 +151,12 @@ struct BnBwdFinArgs {
     const float *gamma, *invstd;
     float *dgamma, *dbeta, *k1, *k2, *k3;
 };
-__global__ void bn_bwd_finish_kernel(BnBwdFinArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(BnBwdFinArgs a) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.C) return;
-    double s = 0.0, sx = 0.0;
-    for (int b = 0; b < a.nblk; ++b) { s += a.partial[((size_t)b * a.C + c) * 2]; sx += a.partial[((size_t)b * a.C + c) * 2 + 1]; }
+    double s, sx;
+    wave_sum2(a.partial, a.nblk, a.C, c, s, sx);
+    if (threadIdx.x & 63) return;
     a.dbeta[c] = (float)s;
     a.dgamma[c] = (float)sx;
     a.k1[c] = a.gamma[c] * a.invstd[c];
@@ -156,12 +165,12 @@ __global__ void bn_bwd_finish_kernel(BnBwdFinArgs a) {
 }
 
 // channel sums -> out[c] (bias gradients), c < Cvalid
-__global__ void sum_finish_kernel(const double *__restrict__ partial, int nblk, int C, int Cvalid, float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void sum_finish_kernel(const double *__restrict__ partial, int nblk, int C, int Cvalid, float *__restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= Cvalid) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * C + c) * 2];
-    out[c] = (float)s;
+    double s, unused;
+    wave_sum2(partial, nblk, C, c, s, unused);
+    if ((threadIdx.x & 63) == 0) out[c] = (float)s;
 }
 
 // ---- BatchNorm apply: y = act(x * scale + shift [+ res]) ------------------------------------------------------------------

@@ -165,28 +165,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
                 }
 }
 
-// dw[co][ref ci][tap] = sum over the split slices, in order; k_map: this engine's input channel -> the reference's (nullptr = identity)
+// dw[co][ref ci][tap] = sum over the split slices, in a fixed order; k_map: this engine's input channel -> the reference's (nullptr = identity).
+// Block = 16 consecutive elements x 16 split lanes: lane l adds slices l, l + 16, ... (independent loads in flight), thread (element, lane 0) adds the
+// 16 lane sums in order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S, int KK, int co_pad, int ci_pad, int Cout, int Cin, const int *__restrict__ k_map,
                                                             float *__restrict__ dw) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= co_pad * ci_pad) return;
-    const int co = idx / ci_pad, ci = idx - co * ci_pad;
+    __shared__ float sh[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const size_t tap_stride = (size_t)co_pad * ci_pad, split_stride = tap_stride * KK;
+    const size_t e = (size_t)blockIdx.x * 16 + el;                   // element of one slice: (tap, co, ci)
+    float s = 0.f;
+    if (e < split_stride) {
+        const float *p = partial + e;
+        int sp = sl;
+        for (; sp + 48 < S; sp += 64) {
+            const float v0 = p[(size_t)sp * split_stride], v1 = p[(size_t)(sp + 16) * split_stride], v2 = p[(size_t)(sp + 32) * split_stride], v3 = p[(size_t)(sp + 48) * split_stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; sp < S; sp += 16) s += p[(size_t)sp * split_stride];
+    }
+    sh[sl][el] = s;
+    __syncthreads();
+    if (sl != 0 || e >= split_stride) return;
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += sh[l][el];
+    const int tp = (int)(e / tap_stride);
+    const int rem = (int)(e - (size_t)tp * tap_stride);
+    const int co = rem / ci_pad, ci = rem - co * ci_pad;
     if (co >= Cout) return;
     const int ref = k_map ? k_map[ci] : (ci < Cin ? ci : -1);
     if (ref < 0) return;
-    const float *p = partial + idx;
-    const size_t tap_stride = (size_t)co_pad * ci_pad, split_stride = tap_stride * KK;
-    for (int tp = 0; tp < KK; ++tp) {
-        float s = 0.f;
-        int sp = 0;
-        for (; sp + 4 <= S; sp += 4) {                     // four slices in flight, added in order
-            const float v0 = p[(size_t)sp * split_stride + tp * tap_stride], v1 = p[(size_t)(sp + 1) * split_stride + tp * tap_stride];
-            const float v2 = p[(size_t)(sp + 2) * split_stride + tp * tap_stride], v3 = p[(size_t)(sp + 3) * split_stride + tp * tap_stride];
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; sp < S; ++sp) s += p[(size_t)sp * split_stride + tp * tap_stride];
-        dw[((size_t)co * Cin + ref) * KK + tp] = s;
-    }
+    dw[((size_t)co * Cin + ref) * KK + tp] = t;
 }
 
 // Plans the weight gradient of one layer and appends its two launches to `ops`.  *partial_floats grows to what the layer needs; the
@@ -229,7 +239,7 @@ inline int plan_wgrad(pn_ctx *ctx, int B, int H, int W, const bf *x, int x_plane
             if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(wgrad_kernel<1, 4>), lds)) return rc;
             hipLaunchKernelGGL((wgrad_kernel<1, 4>), dim3(S, pairs), dim3(256), lds, s, a);
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.co_pad * a.ci_pad + 255) / 256), dim3(256), 0, s, (const float *)a.partial, S, KK, a.co_pad, a.ci_pad, Cout, Cin, k_map, dw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((size_t)KK * a.co_pad * a.ci_pad + 15) / 16)), dim3(256), 0, s, (const float *)a.partial, S, KK, a.co_pad, a.ci_pad, Cout, Cin, k_map, dw);
         PN_HIP_CHECK(ctx, hipGetLastError());
         return (int)PN_OK;
     });
