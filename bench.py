@@ -287,12 +287,16 @@ def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=Fal
     extra = {"cpu_baseline": train_step_cpu(batch)} if cpu else {}
     if precision == "fp32" and batch_in is None and world == 1:      # the opt-in fast mode on the same batch, next to the parity mode
         fast = train_step_leg(dev, steps, warmup, world, group, lr, False, "bf16x3", (batch, t_targets))
-        extra["bf16x3"] = {k: fast[k] for k in ("ms_per_step", "frames_per_s_per_gpu", "tflops", "loss_first_step", "loss_last_step")}
-        extra["bf16x3"]["what"] = "TrainEngine(precision='bf16x3'): the 3x3 convolutions (forward, data and weight gradient) on split-bf16 MFMA, fp32 tensors"
+        extra["bf16x3"] = {k: fast[k] for k in ("ms_per_step", "frames_per_s_per_gpu", "tflops", "loss_first_step", "loss_last_step", "launch_mode")}
+        extra["bf16x3"]["physical_bf16_tflops"] = round(3 * fast["tflops"], 1)
+        extra["bf16x3"]["frac_of_bf16_peak_physical"] = round(3 * fast["tflops"] / PEAK_TFLOPS["bf16"], 4)
+        extra["bf16x3"]["what"] = ("TrainEngine(precision='bf16x3'), round 6: the whole step on NHWC [hi | lo] bf16 planes (csrc/trainx.hip) -- forward and data-gradient convolutions "
+                                   "on the inference kernels (conv3 / conv4 / conv_mfma), pixel-K MFMA weight gradient (ds_read_b64_tr_b16), channel-minor BatchNorm / pool / head passes")
     return {**extra, "ms_per_step": round(dt * 1e3, 3), "frames_per_s_per_gpu": round(BATCH / dt, 1), "tflops": round(flops / dt / 1e12, 1), "dtype": "f32",
             "peak_tflops_f32_mfma": 157.0, "batch_per_gpu": BATCH, "input": "224x224", "parameters": int(eng.n_params),
             "loss_first_step": round(first, 5), "loss_last_step": round(float(t.sum()), 5), "targets_on_gpu_ms_per_batch": round(t_targets * 1e3, 3),
-            "launch_mode": "hipGraph replay of the step" if world == 1 else "hipGraph replay of forward + backward, all-reduce and update eager",
+            "launch_mode": ("one C call per step, launches issued from C++ on two HIP streams (eager), update eager" if eng.planes else
+                            "hipGraph replay of the step" if world == 1 else "hipGraph replay of forward + backward, all-reduce and update eager"),
             "what": "TrainEngine.step: train-mode forward (batch-statistics BatchNorm), fg-weighted loss, backward (MFMA dgrad / wgrad), Nesterov SGD; %s"
                     % ("one all-reduce of the flat gradient per step over %d ranks" % world if world > 1 else "single GPU")}
 

@@ -52,6 +52,7 @@ struct TxLayer {                      // one nn.Conv2d
     float *dw = nullptr, *db = nullptr;
     int x = -1;                       // input tensor
     bool cat = false;                 // reads the stage-2 input in this engine's channel order [feat | paf | heat | z | pad]
+    bool bn_follows = false;          // its output goes straight into a train-mode BatchNorm: the batch mean cancels the bias, d loss / d bias == 0 exactly
     bf *pack_f = nullptr, *pack_d = nullptr;      // forward / data-gradient weight packs (built lazily by the group that needs them)
     float *bias_pad = nullptr;
 };
@@ -89,6 +90,11 @@ struct pn_trainer {
     double *partial = nullptr; size_t partial_doubles = 0;
     float *nchw_a = nullptr, *nchw_b = nullptr; size_t nchw_elems = 0;      // NCHW f32 scratch: the stem hand-over and the legacy weight gradient
     float *wg_partial = nullptr; size_t wg_partial_floats = 0;
+    // the weight gradients run on a second stream beside the BatchNorm / data-gradient chain (matrix-core-bound next to bandwidth-bound launches)
+    hipStream_t side = nullptr;
+    bool two_streams = true;
+    std::vector<hipEvent_t> events;
+    size_t side_tail = (size_t)-1;            // ops.size() right after the last side-stream op: nothing new on the step's stream since = no new fork needed
     float *head_out[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     // per-step arguments (read by the ops when they launch)
     const float *img = nullptr, *target[3] = {nullptr, nullptr, nullptr}, *fg = nullptr;
@@ -323,65 +329,100 @@ int red_blocks(const pn_trainer *t, long npix, int C, int *ppb) {
 
 int need_partial(pn_trainer *t, size_t doubles) { t->partial_doubles = std::max(t->partial_doubles, doubles); return PN_OK; }
 
-void op_bn_fwd(pn_trainer *t, int bn, int x, int res, int y, int act) {
-    const TxTensor X = t->T[x], Y = t->T[y];
-    const long npix = (long)t->B * X.H * X.W;
-    const int C = t->bns[bn].C;
-    int ppb;
-    const int nblk = red_blocks(t, npix, C, &ppb);
-    need_partial(t, (size_t)nblk * C * 2);
+struct BnUse { int bn, x, res, y, act; };                 // forward: y = act(bn(x) [+ res])
+struct BnBwdUse { int bn, x, dy, y, dx, dres, act; bool has_res; };
+
+// up to three independent BatchNorm layers (the branches of a stage level) per launch: blockIdx.y = layer
+void op_bn_fwd(pn_trainer *t, std::vector<BnUse> uses) {
+    const int n = (int)uses.size();
+    struct Geo { long npix; int C, ppb, nblk; size_t poff; } g[3];
+    size_t poff = 0;
+    int max_nblk = 0, max_c = 0;
+    long max_items = 0;
+    for (int i = 0; i < n; ++i) {
+        const TxTensor X = t->T[uses[i].x];
+        g[i].npix = (long)t->B * X.H * X.W; g[i].C = t->bns[uses[i].bn].C;
+        g[i].nblk = red_blocks(t, g[i].npix, g[i].C, &g[i].ppb);
+        g[i].poff = poff; poff += (size_t)g[i].nblk * g[i].C * 2;
+        max_nblk = std::max(max_nblk, g[i].nblk); max_c = std::max(max_c, g[i].C); max_items = std::max(max_items, g[i].npix * (g[i].C / 8));
+    }
+    need_partial(t, poff);
     t->ops.push_back([=](hipStream_t s) {
-        const TxBn &b = t->bns[bn];
-        tx::RedArgs r;
-        memset(&r, 0, sizeof r);
-        r.x = X.p; r.x_cs = X.cs(); r.x_split = X.plane; r.C = C; r.npix = npix; r.ppb = ppb; r.partial = t->partial;
-        hipLaunchKernelGGL(tx::reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, r);
-        tx::BnFinArgs f;
-        f.partial = t->partial; f.nblk = nblk; f.C = C; f.n = (double)npix; f.gamma = b.gamma; f.beta = b.beta;
-        f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift; f.running_mean = b.rm; f.running_var = b.rv;
-        f.momentum = t->momentum; f.eps = t->eps;
-        hipLaunchKernelGGL(tx::bn_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, f);
-        tx::BnApplyArgs a;
-        memset(&a, 0, sizeof a);
-        a.x = X.p; a.x_cs = X.cs(); a.x_split = X.plane;
-        if (res >= 0) { const TxTensor R = t->T[res]; a.res = R.p; a.res_cs = R.cs(); a.res_split = R.plane; }
-        a.y = Y.p; a.y_cs = Y.cs(); a.y_split = Y.plane; a.scale = b.scale; a.shift = b.shift; a.act = act; a.C = C; a.npix = npix;
-        hipLaunchKernelGGL(tx::bn_apply_kernel, dim3(grid_for(npix * (C / 8), t->ctx->num_cus)), dim3(256), 0, s, a);
+        tx::Multi<tx::RedArgs> r;
+        tx::Multi<tx::BnFinArgs> f;
+        tx::Multi<tx::BnApplyArgs> a;
+        memset(&r, 0, sizeof r); memset(&f, 0, sizeof f); memset(&a, 0, sizeof a);
+        for (int i = 0; i < n; ++i) {
+            const TxBn &b = t->bns[uses[i].bn];
+            const TxTensor X = t->T[uses[i].x], Y = t->T[uses[i].y];
+            tx::RedArgs &ri = r.a[i];
+            ri.x = X.p; ri.x_cs = X.cs(); ri.x_split = X.plane; ri.C = g[i].C; ri.npix = g[i].npix; ri.ppb = g[i].ppb; ri.nblk = g[i].nblk; ri.partial = t->partial + g[i].poff;
+            tx::BnFinArgs &fi = f.a[i];
+            fi.partial = t->partial + g[i].poff; fi.nblk = g[i].nblk; fi.C = g[i].C; fi.n = (double)g[i].npix; fi.gamma = b.gamma; fi.beta = b.beta;
+            fi.mean = b.mean; fi.invstd = b.invstd; fi.scale = b.scale; fi.shift = b.shift; fi.running_mean = b.rm; fi.running_var = b.rv;
+            fi.momentum = t->momentum; fi.eps = t->eps;
+            tx::BnApplyArgs &ai = a.a[i];
+            ai.x = X.p; ai.x_cs = X.cs(); ai.x_split = X.plane;
+            if (uses[i].res >= 0) { const TxTensor R = t->T[uses[i].res]; ai.res = R.p; ai.res_cs = R.cs(); ai.res_split = R.plane; }
+            ai.y = Y.p; ai.y_cs = Y.cs(); ai.y_split = Y.plane; ai.scale = b.scale; ai.shift = b.shift; ai.act = uses[i].act; ai.C = g[i].C; ai.npix = g[i].npix;
+        }
+        hipLaunchKernelGGL(tx::reduce_kernel<0>, dim3(max_nblk, n), dim3(256), 0, s, r);
+        hipLaunchKernelGGL(tx::bn_finish_kernel, dim3((max_c + 3) / 4, n), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(tx::bn_apply_kernel, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
 }
+void op_bn_fwd(pn_trainer *t, int bn, int x, int res, int y, int act) { op_bn_fwd(t, std::vector<BnUse>{{bn, x, res, y, act}}); }
 
-void op_bn_bwd(pn_trainer *t, int bn, int x, int dy, int y, int dx, int dres, int act) {
-    const TxTensor X = t->T[x], DY = t->T[dy], Y = t->T[y], DX = t->T[dx];
-    const long npix = (long)t->B * X.H * X.W;
-    const int C = t->bns[bn].C;
-    int ppb;
-    const int nblk = red_blocks(t, npix, C, &ppb);
-    need_partial(t, (size_t)nblk * C * 2);
+void op_bn_bwd(pn_trainer *t, std::vector<BnBwdUse> uses) {
+    const int n = (int)uses.size();
+    struct Geo { long npix; int C, ppb, nblk; size_t poff; } g[3];
+    size_t poff = 0;
+    int max_nblk = 0, max_c = 0;
+    long max_items = 0;
+    for (int i = 0; i < n; ++i) {
+        const TxTensor X = t->T[uses[i].x];
+        g[i].npix = (long)t->B * X.H * X.W; g[i].C = t->bns[uses[i].bn].C;
+        g[i].nblk = red_blocks(t, g[i].npix, g[i].C, &g[i].ppb);
+        g[i].poff = poff; poff += (size_t)g[i].nblk * g[i].C * 2;
+        max_nblk = std::max(max_nblk, g[i].nblk); max_c = std::max(max_c, g[i].C); max_items = std::max(max_items, g[i].npix * (g[i].C / 8));
+    }
+    need_partial(t, poff);
     t->ops.push_back([=](hipStream_t s) {
-        const TxBn &b = t->bns[bn];
-        tx::RedArgs r;
-        memset(&r, 0, sizeof r);
-        r.x = X.p; r.x_cs = X.cs(); r.x_split = X.plane; r.dy = DY.p; r.dy_cs = DY.cs(); r.dy_split = DY.plane;
-        r.y = act ? Y.p : nullptr; r.y_cs = Y.cs(); r.mean = b.mean; r.invstd = b.invstd; r.act = act;
-        r.C = C; r.npix = npix; r.ppb = ppb; r.partial = t->partial;
-        hipLaunchKernelGGL(tx::reduce_kernel<1>, dim3(nblk), dim3(256), 0, s, r);
-        tx::BnBwdFinArgs f;
-        f.partial = t->partial; f.nblk = nblk; f.C = C; f.n = (double)npix; f.gamma = b.gamma; f.invstd = b.invstd;
-        f.dgamma = b.dgamma; f.dbeta = b.dbeta; f.k1 = b.k1; f.k2 = b.k2; f.k3 = b.k3;
-        hipLaunchKernelGGL(tx::bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, f);
-        tx::BnBwdApplyArgs a;
-        memset(&a, 0, sizeof a);
-        a.x = X.p; a.x_cs = X.cs(); a.x_split = X.plane; a.dy = DY.p; a.dy_cs = DY.cs(); a.dy_split = DY.plane;
-        a.y = act ? Y.p : nullptr; a.y_cs = Y.cs(); a.mean = b.mean; a.invstd = b.invstd; a.k1 = b.k1; a.k2 = b.k2; a.k3 = b.k3;
-        a.dx = DX.p; a.dx_cs = DX.cs(); a.dx_split = DX.plane;
-        if (dres >= 0) { const TxTensor R = t->T[dres]; a.dres = R.p; a.dres_cs = R.cs(); a.dres_split = R.plane; }
-        a.act = act; a.C = C; a.npix = npix;
-        hipLaunchKernelGGL(tx::bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 8), t->ctx->num_cus)), dim3(256), 0, s, a);
+        tx::Multi<tx::RedArgs> r;
+        tx::Multi<tx::BnBwdFinArgs> f;
+        tx::Multi<tx::BnBwdApplyArgs> a;
+        memset(&r, 0, sizeof r); memset(&f, 0, sizeof f); memset(&a, 0, sizeof a);
+        for (int i = 0; i < n; ++i) {
+            const BnBwdUse &u = uses[i];
+            const TxBn &b = t->bns[u.bn];
+            const TxTensor X = t->T[u.x], DY = t->T[u.dy], Y = t->T[u.y], DX = t->T[u.dx];
+            // the activation's sign: from the stored output when a residual went into it, else recomputed from x (one tensor less to read)
+            const bf *ysrc = (u.act && u.has_res) ? Y.p : nullptr;
+            tx::RedArgs &ri = r.a[i];
+            ri.x = X.p; ri.x_cs = X.cs(); ri.x_split = X.plane; ri.dy = DY.p; ri.dy_cs = DY.cs(); ri.dy_split = DY.plane;
+            ri.y = ysrc; ri.y_cs = Y.cs(); ri.mean = b.mean; ri.invstd = b.invstd; ri.scale = b.scale; ri.shift = b.shift; ri.act = u.act;
+            ri.C = g[i].C; ri.npix = g[i].npix; ri.ppb = g[i].ppb; ri.nblk = g[i].nblk; ri.partial = t->partial + g[i].poff;
+            tx::BnBwdFinArgs &fi = f.a[i];
+            fi.partial = t->partial + g[i].poff; fi.nblk = g[i].nblk; fi.C = g[i].C; fi.n = (double)g[i].npix; fi.gamma = b.gamma; fi.invstd = b.invstd;
+            fi.dgamma = b.dgamma; fi.dbeta = b.dbeta; fi.k1 = b.k1; fi.k2 = b.k2; fi.k3 = b.k3;
+            tx::BnBwdApplyArgs &ai = a.a[i];
+            ai.x = X.p; ai.x_cs = X.cs(); ai.x_split = X.plane; ai.dy = DY.p; ai.dy_cs = DY.cs(); ai.dy_split = DY.plane;
+            ai.y = ysrc; ai.y_cs = Y.cs(); ai.mean = b.mean; ai.invstd = b.invstd; ai.k1 = b.k1; ai.k2 = b.k2; ai.k3 = b.k3; ai.scale = b.scale; ai.shift = b.shift;
+            ai.dx = DX.p; ai.dx_cs = DX.cs(); ai.dx_split = DX.plane;
+            if (u.dres >= 0) { const TxTensor R = t->T[u.dres]; ai.dres = R.p; ai.dres_cs = R.cs(); ai.dres_split = R.plane; }
+            ai.act = u.act; ai.C = g[i].C; ai.npix = g[i].npix;
+        }
+        hipLaunchKernelGGL(tx::reduce_kernel<1>, dim3(max_nblk, n), dim3(256), 0, s, r);
+        hipLaunchKernelGGL(tx::bn_bwd_finish_kernel, dim3((max_c + 3) / 4, n), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(tx::bn_bwd_apply_kernel, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
+}
+void op_bn_bwd(pn_trainer *t, int bn, int x, int dy, int y, int dx, int dres, int act, bool has_res) {
+    op_bn_bwd(t, std::vector<BnBwdUse>{{bn, x, dy, y, dx, dres, act, has_res}});
 }
 
 // bias gradient of layer `l` from its output gradient tensor dy (first cout channels)
@@ -394,10 +435,11 @@ void op_dbias(pn_trainer *t, int l, int dy) {
     need_partial(t, (size_t)nblk * C * 2);
     t->ops.push_back([=](hipStream_t s) {
         const TxLayer &L = t->layers[l];
-        tx::RedArgs r;
+        tx::Multi<tx::RedArgs> r;
         memset(&r, 0, sizeof r);
-        r.x = DY.p; r.x_cs = DY.cs(); r.x_split = DY.plane; r.C = C; r.npix = npix; r.ppb = ppb; r.partial = t->partial;
-        hipLaunchKernelGGL(tx::reduce_kernel<2>, dim3(nblk), dim3(256), 0, s, r);
+        tx::RedArgs &ri = r.a[0];
+        ri.x = DY.p; ri.x_cs = DY.cs(); ri.x_split = DY.plane; ri.C = C; ri.npix = npix; ri.ppb = ppb; ri.nblk = nblk; ri.partial = t->partial;
+        hipLaunchKernelGGL(tx::reduce_kernel<2>, dim3(nblk, 1), dim3(256), 0, s, r);
         hipLaunchKernelGGL(tx::sum_finish_kernel, dim3((L.cout + 3) / 4), dim3(256), 0, s, (const double *)t->partial, nblk, C, L.cout, L.db);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
@@ -458,6 +500,41 @@ void op_head(pn_trainer *t, int stage, int b, int dcat, int dv) {
     });
 }
 
+// fork: the side stream may start once everything issued so far on the step's stream has finished; join: the other way round
+int op_fork(pn_trainer *t) {
+    if (!t->two_streams || t->ops.size() == t->side_tail) return PN_OK;
+    hipEvent_t ev;
+    PN_HIP_CHECK(t->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    t->events.push_back(ev);
+    t->ops.push_back([t, ev](hipStream_t s) {
+        PN_HIP_CHECK(t->ctx, hipEventRecord(ev, s));
+        PN_HIP_CHECK(t->ctx, hipStreamWaitEvent(t->side, ev, 0));
+        return (int)PN_OK;
+    });
+    return PN_OK;
+}
+int op_join(pn_trainer *t) {
+    if (!t->two_streams) return PN_OK;
+    hipEvent_t ev;
+    PN_HIP_CHECK(t->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    t->events.push_back(ev);
+    t->ops.push_back([t, ev](hipStream_t s) {
+        PN_HIP_CHECK(t->ctx, hipEventRecord(ev, t->side));
+        PN_HIP_CHECK(t->ctx, hipStreamWaitEvent(s, ev, 0));
+        return (int)PN_OK;
+    });
+    return PN_OK;
+}
+// every op appended since `from` runs on the side stream
+void ops_to_side(pn_trainer *t, size_t from) {
+    if (!t->two_streams) return;
+    for (size_t i = from; i < t->ops.size(); ++i) {
+        auto f = t->ops[i];
+        t->ops[i] = [t, f](hipStream_t) { return f(t->side); };
+    }
+    t->side_tail = t->ops.size();
+}
+
 // weight gradient of layer l: x = its input tensor, dy = gradient of its output
 int op_wgrad(pn_trainer *t, int l, int dy) {
     const TxLayer &L = t->layers[l];
@@ -478,8 +555,13 @@ int op_wgrad(pn_trainer *t, int l, int dy) {
         });
         return PN_OK;
     }
-    if (L.b) op_dbias(t, l, dy);
-    return tx::plan_wgrad(t->ctx, t->B, X.H, X.W, X.p, X.plane, DY.p, DY.plane, L.cin, L.cout, L.ks, L.cat ? t->cat_k_map : nullptr, L.dw, &t->wg_partial, &t->wg_partial_floats, t->ops);
+    if (L.b && !L.bn_follows) op_dbias(t, l, dy);      // (a bias in front of a BatchNorm: its gradient is identically zero and the flat gradient buffer already holds 0)
+    if (int rc = op_fork(t)) return rc;
+    const size_t from = t->ops.size();
+    if (int rc = tx::plan_wgrad(t->ctx, t->B, X.H, X.W, X.p, X.plane, DY.p, DY.plane, L.cin, L.cout, L.ks, L.cat ? t->cat_k_map : nullptr, L.dw, &t->wg_partial, &t->wg_partial_floats, t->ops))
+        return rc;
+    ops_to_side(t, from);
+    return PN_OK;
 }
 
 int build(pn_trainer *t) {
@@ -593,6 +675,7 @@ int build(pn_trainer *t) {
                 const int cout = lv < 4 ? BR_C[b][lv] : HEAD_C[b];
                 TX(new_layer(t, nm, BR_KS[b][lv], cin, cout, true, in, lv == 0 && st == 1, &br[st][b].l[lv]));
                 if (lv < 4) {
+                    t->layers[br[st][b].l[lv]].bn_follows = true;
                     snprintf(nm, sizeof nm, "model%d_%d.%d", st + 1, b + 1, 3 * lv + 1);
                     TX(new_bn(t, nm, cout, &br[st][b].bn[lv]));
                     uses.push_back({br[st][b].l[lv], false, in, br[st][b].C[lv], 0, -1, PN_ACT_NONE, nullptr});
@@ -603,8 +686,11 @@ int build(pn_trainer *t) {
                 }
             }
             TX(add_conv_group(t, uses));
-            if (lv < 4)
-                for (int b = 0; b < 3; ++b) op_bn_fwd(t, br[st][b].bn[lv], br[st][b].C[lv], -1, br[st][b].A[lv], 2);
+            if (lv < 4) {
+                std::vector<BnUse> bu;
+                for (int b = 0; b < 3; ++b) bu.push_back({br[st][b].bn[lv], br[st][b].C[lv], -1, br[st][b].A[lv], 2});
+                op_bn_fwd(t, bu);
+            }
         }
     }
 
@@ -618,12 +704,14 @@ int build(pn_trainer *t) {
         }
         for (int lv = 4; lv >= 0; --lv) {
             int dc[3];
+            std::vector<BnBwdUse> bu;
             for (int b = 0; b < 3; ++b) {
                 if (lv < 4) {
                     if ((rc2 = TT(H8, W8, BR_C[b][lv], &dc[b]))) return rc2;
-                    op_bn_bwd(t, br[st][b].bn[lv], br[st][b].C[lv], dy[b], br[st][b].A[lv], dc[b], -1, 2);
+                    bu.push_back({br[st][b].bn[lv], br[st][b].C[lv], dy[b], br[st][b].A[lv], dc[b], -1, 2, false});
                 } else dc[b] = dy[b];
             }
+            if (!bu.empty()) op_bn_bwd(t, bu);
             for (int b = 0; b < 3; ++b)
                 if ((rc2 = op_wgrad(t, br[st][b].l[lv], dc[b]))) return rc2;
             std::vector<ConvUse> uses;
@@ -647,7 +735,7 @@ int build(pn_trainer *t) {
     int dA7, dC7, dA6;
     TX(TT(H4, W4, 128, &dA7)); TX(TT(H4, W4, 128, &dC7)); TX(TT(H4, W4, 128, &dA6));
     op_pool_bwd(t, DFEAT, dA7);
-    op_bn_bwd(t, bn_c2, C7, dA7, A7, dC7, -1, 1);
+    op_bn_bwd(t, bn_c2, C7, dA7, A7, dC7, -1, 1, false);
     TX(op_wgrad(t, l_c2, dC7));
     TX(add_conv_group(t, {{l_c2, true, dC7, dA6, 0, -1, PN_ACT_NONE, nullptr}}));
 
@@ -655,14 +743,14 @@ int build(pn_trainer *t) {
         int rc2;
         // scratch: dC2, g (identity gradient / dD), dA1, dC1, dCD, tmp  (reused between the two 112x112 blocks)
         int dC2 = scratch[0], g = scratch[1], dA1 = scratch[2], dC1 = scratch[3];
-        op_bn_bwd(t, b.bn2, b.C2, dout, b.out, dC2, g, 1);
+        op_bn_bwd(t, b.bn2, b.C2, dout, b.out, dC2, g, 1, true);
         if ((rc2 = op_wgrad(t, b.l2, dC2))) return rc2;
         if ((rc2 = add_conv_group(t, {{b.l2, true, dC2, dA1, 0, -1, PN_ACT_NONE, nullptr}}))) return rc2;
-        op_bn_bwd(t, b.bn1, b.C1, dA1, b.A1, dC1, -1, 1);
+        op_bn_bwd(t, b.bn1, b.C1, dA1, b.A1, dC1, -1, 1, false);
         if ((rc2 = op_wgrad(t, b.l1, dC1))) return rc2;
         if (b.lds >= 0) {
             int dCD = scratch[4], tmp = scratch[5];
-            op_bn_bwd(t, b.bnds, b.CD, g, b.D, dCD, -1, 0);
+            op_bn_bwd(t, b.bnds, b.CD, g, b.D, dCD, -1, 0, false);
             if ((rc2 = op_wgrad(t, b.lds, dCD))) return rc2;
             if ((rc2 = add_conv_group(t, {{b.lds, true, dCD, tmp, 0, -1, PN_ACT_NONE, nullptr}}))) return rc2;
             if ((rc2 = add_conv_group(t, {{b.l1, true, dC1, *din, 0, tmp, PN_ACT_NONE, nullptr}}))) return rc2;     // dx = dgrad(conv1) + dgrad(shortcut)
@@ -677,16 +765,16 @@ int build(pn_trainer *t) {
     TX(TT(H4, W4, 128, &s56[4])); TX(TT(H4, W4, 64, &s56[5]));
     TX(TT(H4, W4, 64, &dP1));
     TX(block_bwd(b20, dA6, H4, W4, 64, 128, &dP1, s56));
-    int s112[6], dA4, dA2, dA0, dC0;
-    for (int i = 0; i < 4; ++i) TX(TT(H2, W2, 64, &s112[i]));
-    s112[4] = s112[5] = -1;
-    TX(TT(H2, W2, 64, &dA4)); TX(TT(H2, W2, 64, &dA2));
+    // (own scratch per block: a weight gradient still running on the side stream reads dC2 / dC1 of its block)
+    int s112[6], s112b[6], dA4, dA2, dA0, dC0;
+    for (int i = 0; i < 4; ++i) { TX(TT(H2, W2, 64, &s112[i])); TX(TT(H2, W2, 64, &s112b[i])); }
+    s112[4] = s112[5] = s112b[4] = s112b[5] = -1;
+    TX(TT(H2, W2, 64, &dA4)); TX(TT(H2, W2, 64, &dA2)); TX(TT(H2, W2, 64, &dC0));
     op_pool_bwd(t, dP1, dA4);
     TX(block_bwd(b11, dA4, H2, W2, 64, 64, &dA2, s112));
-    dA0 = dA4;                                   // free again: layer1.1's output gradient has been consumed
-    TX(block_bwd(b10, dA2, H2, W2, 64, 64, &dA0, s112));
-    dC0 = s112[0];
-    op_bn_bwd(t, bn_stem, C0, dA0, A0, dC0, -1, 1);
+    dA0 = dA4;                                   // free again: layer1.1's output gradient has been consumed (by launches of the step's own stream)
+    TX(block_bwd(b10, dA2, H2, W2, 64, 64, &dA0, s112b));
+    op_bn_bwd(t, bn_stem, C0, dA0, A0, dC0, -1, 1, false);
     {
         const TxTensor d0 = t->T[dC0];
         t->ops.push_back([=](hipStream_t s) {
@@ -696,6 +784,7 @@ int build(pn_trainer *t) {
             return pn_conv2d_wgrad(t->ctx, t->img, t->nchw_b, dw_stem, nullptr, B, 1, H, W, 64, 7, 2, 3, (void *)s);
         });
     }
+    TX(op_join(t));                               // the step ends when the last weight gradient has landed
 #undef TX
     // scratch and descriptor tables
     if ((rc = tx_alloc(t, (void **)&t->partial, std::max<size_t>(t->partial_doubles, 1) * 8, true))) return rc;
@@ -729,6 +818,8 @@ pn_trainer *pn_trainer_create(pn_ctx *ctx) {
 void pn_trainer_destroy(pn_trainer *t) {
     if (!t) return;
     for (void *p : t->allocs) (void)hipFree(p);
+    for (hipEvent_t ev : t->events) (void)hipEventDestroy(ev);
+    if (t->side) (void)hipStreamDestroy(t->side);
     delete t;
 }
 
@@ -755,6 +846,9 @@ int pn_trainer_finalize(pn_trainer *t, float *flat_param_dev, float *flat_grad_d
     t->flat_p = flat_param_dev; t->flat_g = flat_grad_dev; t->B = B; t->H = H; t->W = W; t->momentum = bn_momentum; t->eps = bn_eps;
     const char *e = getenv("POPNET_TRAINX_WGRAD");
     t->legacy_wgrad = e && !strcmp(e, "legacy");
+    const char *e2 = getenv("POPNET_TRAINX_STREAMS");
+    t->two_streams = !(e2 && atoi(e2) == 1) && !t->legacy_wgrad;
+    if (t->two_streams) PN_HIP_CHECK(ctx, hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     if (int rc = build(t)) return rc;
     t->finalized = true;
     return PN_OK;

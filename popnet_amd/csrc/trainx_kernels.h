@@ -47,29 +47,39 @@ __device__ __forceinline__ void st8x(bf *p, int split, const float (&v)[8]) {
 // MODE 2: s0 = sum x                                     (bias gradient)
 // Block = 256 threads = (C / 8 channel groups) x (256 / (C / 8) pixel lanes); block b owns pixels [b * ppb, (b + 1) * ppb).
 // partial[(block * C + c) * 2 + {0, 1}] (double).
+// Independent tensors of a level (the three branches of a stage) share a launch: blockIdx.y = problem.
+template <typename A> struct Multi { A a[3]; };
+
 struct RedArgs {
     const bf *x; int x_cs, x_split;          // MODE 0 / 2: the tensor; MODE 1: the convolution output (pre-BN)
     const bf *dy; int dy_cs, dy_split;       // MODE 1: gradient w.r.t. the activation output
-    const bf *y; int y_cs;                   // MODE 1: activation output, hi plane (sign only) -- nullptr when act == 0
+    const bf *y; int y_cs;                   // MODE 1: activation output, hi plane (sign only); nullptr = recompute the sign from x (scale / shift)
     const float *mean, *invstd;              // MODE 1
+    const float *scale, *shift;              // MODE 1, y == nullptr: the forward's affine (y = x * scale + shift, no residual)
     int act;                                 // MODE 1: 0 none, 1 ReLU, 2 LeakyReLU(0.1)
-    int C; long npix; int ppb;
+    int C; long npix; int ppb, nblk;
     double *partial;
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void reduce_kernel(RedArgs a) {
+__global__ __launch_bounds__(256) void reduce_kernel(Multi<RedArgs> mm) {
     __shared__ float sh[2][256][9];
+    const RedArgs &a = mm.a[blockIdx.y];
+    if ((int)blockIdx.x >= a.nblk) return;
     const int G = a.C >> 3, PL = 256 / G;
     const int cg = threadIdx.x % G, pl = threadIdx.x / G;
     const long p0 = (long)blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.npix);
     float s0[8], s1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s0[i] = s1[i] = 0.f;
-    float mu[8], is[8];
+    float mu[8], is[8], sc[8], sf[8];
     if (MODE == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { mu[i] = a.mean[cg * 8 + i]; is[i] = a.invstd[cg * 8 + i]; }
+        if (a.act && !a.y) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = a.scale[cg * 8 + i]; sf[i] = a.shift[cg * 8 + i]; }
+        }
     }
     if (pl < PL)
         for (long p = p0 + pl; p < p1; p += PL) {
@@ -86,7 +96,11 @@ __global__ __launch_bounds__(256) void reduce_kernel(RedArgs a) {
                 ld8x(a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
                 if (a.act) {
                     float y[8];
-                    ld8(a.y + p * a.y_cs + cg * 8, y);
+                    if (a.y) ld8(a.y + p * a.y_cs + cg * 8, y);
+                    else {                                   // no residual: the forward's own expression on the same operands gives the same sign
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) y[i] = x[i] * sc[i] + sf[i];
+                    }
                     const float neg = a.act == 2 ? 0.1f : 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) g[i] = y[i] > 0.f ? g[i] : g[i] * neg;
@@ -122,7 +136,8 @@ __device__ __forceinline__ void wave_sum2(const double *__restrict__ partial, in
     for (int b = lane; b < nblk; b += 64) { s0 += partial[((size_t)b * C + c) * 2]; s1 += partial[((size_t)b * C + c) * 2 + 1]; }
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
 }
-__global__ __launch_bounds__(256) void bn_finish_kernel(BnFinArgs a) {
+__global__ __launch_bounds__(256) void bn_finish_kernel(Multi<BnFinArgs> mm) {
+    const BnFinArgs &a = mm.a[blockIdx.y];
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.C) return;
     double s, ss;
@@ -151,7 +166,8 @@ struct BnBwdFinArgs {
     const float *gamma, *invstd;
     float *dgamma, *dbeta, *k1, *k2, *k3;
 };
-__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(BnBwdFinArgs a) {
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(Multi<BnBwdFinArgs> mm) {
+    const BnBwdFinArgs &a = mm.a[blockIdx.y];
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= a.C) return;
     double s, sx;
@@ -181,7 +197,8 @@ struct BnApplyArgs {
     const float *scale, *shift;
     int act, C; long npix;
 };
-__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(Multi<BnApplyArgs> mm) {
+    const BnApplyArgs &a = mm.a[blockIdx.y];
     const int G = a.C >> 3;
     const long total = a.npix * G;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -217,13 +234,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
 struct BnBwdApplyArgs {
     const bf *x; int x_cs, x_split;
     const bf *dy; int dy_cs, dy_split;
-    const bf *y; int y_cs;
-    const float *mean, *invstd, *k1, *k2, *k3;
+    const bf *y; int y_cs;                   // nullptr = recompute the sign from x (scale / shift), as in reduce_kernel<1>
+    const float *mean, *invstd, *k1, *k2, *k3, *scale, *shift;
     bf *dx; int dx_cs, dx_split;
     bf *dres; int dres_cs, dres_split;       // gradient of the residual input (= g) or nullptr
     int act, C; long npix;
 };
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs a) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(Multi<BnBwdApplyArgs> mm) {
+    const BnBwdApplyArgs &a = mm.a[blockIdx.y];
     const int G = a.C >> 3;
     const long total = a.npix * G;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -234,7 +252,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs a) {
         ld8x(a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
         if (a.act) {
             float y[8];
-            ld8(a.y + p * a.y_cs + cg * 8, y);
+            if (a.y) ld8(a.y + p * a.y_cs + cg * 8, y);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) y[k] = x[k] * a.scale[cg * 8 + k] + a.shift[cg * 8 + k];
+            }
             const float neg = a.act == 2 ? 0.1f : 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = y[k] > 0.f ? g[k] : g[k] * neg;

