@@ -221,7 +221,10 @@ inline int plan_wgrad(pn_ctx *ctx, int B, int H, int W, const bf *x, int x_plane
     a.co_pad = ncot * 64; a.ci_pad = a.ncit * 64;
     if (a.co_pad > dy_plane || a.ci_pad > x_plane) return pn_set_error(ctx, PN_ERR_INVALID, "weight gradient on planes: channel tiles exceed the planes");
     const int pairs = ncot * a.ncit;
-    int S = std::max(1, std::min(a.nstrips, (2 * ctx->num_cus + pairs - 1) / pairs));
+    // split-K slices: ONE block per CU.  Every slice costs a 147 KB partial tile written and read back, and a lone 64 KB block leaves the rest of the CU to
+    // the BatchNorm / data-gradient launches of the step's own stream (same box, eager step: 1/2 block per CU 7.10 ms, 1: 6.49-6.68, 1.5: 6.93, 2: 7.03, 3: 7.39)
+    static const int per_cu_x2 = getenv("POPNET_TRAINX_WG_BLOCKS") ? atoi(getenv("POPNET_TRAINX_WG_BLOCKS")) : 2;      // blocks per CU, in halves (experiments)
+    int S = std::max(1, std::min(a.nstrips, (per_cu_x2 * ctx->num_cus / 2 + pairs - 1) / pairs));
     a.strips_per_block = (a.nstrips + S - 1) / S;
     S = (a.nstrips + a.strips_per_block - 1) / a.strips_per_block;
     *partial_floats = std::max(*partial_floats, (size_t)S * KK * a.co_pad * a.ci_pad);

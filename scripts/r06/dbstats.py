@@ -15,6 +15,8 @@ if traces:
     for f in traces:
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
+            if os.environ.get("BY_GRID"):
+                n = "%s  grid(%s,%s)" % (n[:60], r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"))
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             a = agg.setdefault(n, [0, 0])
             a[0] += 1
@@ -26,5 +28,5 @@ elif dbs:
 rows.sort(key=lambda r: -r[2])
 tot = sum(r[2] for r in rows)
 print("total %.3f ms  (%.3f ms per step over %g steps)" % (tot / 1e6, tot / 1e6 / steps, steps))
-for n, c, t, a in rows[:45]:
+for n, c, t, a in rows[:int(os.environ.get('TOP', '45'))]:
     print("%-84s %7.1f/step %9.3f ms/step %8.1f us %5.1f%%" % (n[:84], c / steps, t / 1e6 / steps, a / 1e3, 100 * t / tot))
