@@ -587,13 +587,16 @@ int build(pn_trainer *t) {
 #define TX(expr) do { if ((rc = (expr))) return rc; } while (0)
 
     // ---------------- forward ----------------
-    // step prologue: every weight pack and padded bias from the live parameters
+    // step prologue: every weight pack and padded bias from the live parameters -- on the side stream, under the stem (which reads the raw parameters)
+    TX(op_fork(t));
+    const size_t pack_from = t->ops.size();
     t->ops.push_back([t](hipStream_t s) {
         if (t->pack_groups) hipLaunchKernelGGL(tx::pack_kernel, dim3((t->pack_groups + 255) / 256), dim3(256), 0, s, (const tx::PackDesc *)t->packs_dev, (int)t->packs.size(), t->pack_groups);
         if (!t->biases.empty()) hipLaunchKernelGGL(tx::bias_kernel, dim3((unsigned)t->biases.size()), dim3(128), 0, s, (const tx::BiasDesc *)t->biases_dev, (int)t->biases.size());
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
+    ops_to_side(t, pack_from);
     // stem: model0.conv1 7x7 / 2 on the NCHW f32 image (train.hip), handed over as planes
     int C0, A0;
     TX(TT(H2, W2, 64, &C0)); TX(TT(H2, W2, 64, &A0));
@@ -613,6 +616,7 @@ int build(pn_trainer *t) {
     int bn_stem;
     TX(new_bn(t, "model0.bn1", 64, &bn_stem));
     op_bn_fwd(t, bn_stem, C0, -1, A0, 1);
+    TX(op_join(t));                               // the packs are ready before the first planes convolution
 
     struct Block { int l1, l2, lds, bn1, bn2, bnds, C1, A1, C2, CD, D, in, out; };
     auto basic_block = [&](const std::string &p, int xin, int cin, int cout, int h, int w, bool down, Block *bk) -> int {

@@ -83,6 +83,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
 
     // DMA lane roles: one instruction = 8 pixels x 8 slots of 16 B (one plane); slot sp of pixel px holds logical slot ((sp >> 1) ^ ((px >> 1) & 3)) << 1 | (sp & 1)
     const int dpx = lane >> 3, dsp = lane & 7;
+    const int dma_px = wave * 8 + dpx;
+    const int dma_slot = (((dsp >> 1) ^ ((dma_px >> 1) & 3)) << 1) | (dsp & 1);
+    const unsigned lane_x = (unsigned)(((dma_px - PAD) * a.x_cs + ci0 + dma_slot * 8) * 2);      // (two's complement: added to the strip base modulo 2^32)
+    const unsigned lane_y = (unsigned)((dma_px * a.dy_cs + co0 + dma_slot * 8) * 2);
+    const unsigned rowx = (unsigned)(a.W * a.x_cs * 2), rowy = (unsigned)(a.W * a.dy_cs * 2);
+    const unsigned planex = (unsigned)(a.x_split * 2), planey = (unsigned)(a.dy_split * 2);
+    const unsigned dma_lds = (unsigned)__builtin_amdgcn_readfirstlane(wave * 1024);
     const int s0 = blockIdx.x * a.strips_per_block, s1 = min(s0 + a.strips_per_block, a.nstrips);
     for (int sid = s0; sid < s1; ++sid) {
         const int b = sid / a.strips_per_img, rem = sid - b * a.strips_per_img;
@@ -90,25 +97,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
         const int oy0 = ty * R, ox0 = tx_ * a.Wt;
         const int Wc = min(a.Wt, a.W - ox0);
         __syncthreads();                                   // every wave has finished reading the previous strip's images
-        // x halo image: HR rows x 2 planes, dy image: R rows x 2 planes; each (row, plane) is four 8-pixel pieces: wave w fetches piece w of every one
+        // x halo image: HR rows x 2 planes, dy image: R rows x 2 planes; each (row, plane) is four 8-pixel pieces: wave w fetches piece w of every one.
+        // Addresses in 32-bit arithmetic (a tensor is < 4 GiB): strip base and row validity on the scalar unit, one lane constant, one select per piece
+        // (the first version spent 1.9 vector instructions per MFMA on 64-bit address arithmetic: 31 % matrix-pipe use from one wave per SIMD)
         {
-            const int pg = wave, px = pg * 8 + dpx;
-            const int lslot = (((dsp >> 1) ^ ((px >> 1) & 3)) << 1) | (dsp & 1);
+            const unsigned bx0 = (unsigned)(((long)(b * a.H + oy0 - PAD) * a.W + ox0) * (long)a.x_cs * 2);
+            const unsigned by0 = (unsigned)(((long)(b * a.H + oy0) * a.W + ox0) * (long)a.dy_cs * 2);
+            const bool okx = dma_px < Wc + 2 * PAD && (unsigned)(ox0 - PAD + dma_px) < (unsigned)a.W;
+            const bool oky = dma_px < Wc;
 #pragma unroll
             for (int i = 0; i < HR * 2; ++i) {
                 const int row = i >> 1, pl = i & 1;
-                const int iy = oy0 - PAD + row, ix = ox0 - PAD + px;
-                const bool inb = px < Wc + 2 * PAD && (unsigned)ix < (unsigned)a.W && (unsigned)iy < (unsigned)a.H;
-                const unsigned off = inb ? (unsigned)((((size_t)(b * a.H + iy) * a.W + ix) * a.x_cs + pl * a.x_split + ci0 + lslot * 8) * 2) : a.x_zero;
-                glds16(a.x, off, (unsigned)(i * 4096 + pg * 1024));
+                const bool rowok = (unsigned)(oy0 - PAD + row) < (unsigned)a.H;            // wave-uniform
+                const unsigned off = (okx && rowok) ? bx0 + (unsigned)row * rowx + (unsigned)pl * planex + lane_x : a.x_zero;
+                glds16(a.x, off, (unsigned)(i * 4096) + dma_lds);
             }
 #pragma unroll
             for (int i = 0; i < R * 2; ++i) {
                 const int row = i >> 1, pl = i & 1;
-                const int iy = oy0 + row, ix = ox0 + px;
-                const bool inb = px < Wc && iy < a.H;
-                const unsigned off = inb ? (unsigned)((((size_t)(b * a.H + iy) * a.W + ix) * a.dy_cs + pl * a.dy_split + co0 + lslot * 8) * 2) : a.dy_zero;
-                glds16(a.dy, off, (unsigned)(XIMG + i * 4096 + pg * 1024));
+                const bool rowok = oy0 + row < a.H;
+                const unsigned off = (oky && rowok) ? by0 + (unsigned)row * rowy + (unsigned)pl * planey + lane_y : a.dy_zero;
+                glds16(a.dy, off, (unsigned)(XIMG + i * 4096) + dma_lds);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
