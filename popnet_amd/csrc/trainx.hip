@@ -89,9 +89,10 @@ struct pn_trainer {
     int *cat_k_map = nullptr, *cat_ref_map = nullptr;           // [192] my channel -> reference channel ; [187] reference -> my channel
     double *partial = nullptr; size_t partial_doubles = 0;
     float *nchw_a = nullptr, *nchw_b = nullptr; size_t nchw_elems = 0;      // NCHW f32 scratch: the stem hand-over and the legacy weight gradient
-    float *wg_partial = nullptr; size_t wg_partial_floats = 0;
+    float *wg_partial[4] = {nullptr, nullptr, nullptr, nullptr}; size_t wg_partial_floats = 0;      // one split-K scratch per side stream
     // the weight gradients run on a second stream beside the BatchNorm / data-gradient chain (matrix-core-bound next to bandwidth-bound launches)
-    hipStream_t side = nullptr;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nside = 1, next_side = 0;            // POPNET_TRAINX_SIDES: weight gradients of different layers dealt round-robin to this many side streams
     bool two_streams = true;
     std::vector<hipEvent_t> events;
     size_t side_tail = (size_t)-1;            // ops.size() right after the last side-stream op: nothing new on the step's stream since = no new fork needed
@@ -479,58 +480,74 @@ void op_pool_bwd(pn_trainer *t, int dy, int dx) {
     });
 }
 
-// loss term and head gradient of (stage, branch); dextra = the slice of the stage-2 input gradient that reaches a stage-1 head
-void op_head(pn_trainer *t, int stage, int b, int dcat, int dv) {
-    const TxTensor DV = t->T[dv];
-    const int HW = DV.H * DV.W, C = HEAD_C[b];
-    const long total = (long)t->B * C * HW;
-    const int nblk = (int)((total + 255) / 256);
-    need_partial(t, (size_t)nblk);
+// loss terms and head gradients of a stage's three heads (one launch); dcat = the stage-2 input gradient whose slices reach the stage-1 heads (or -1)
+void op_heads(pn_trainer *t, int stage, int dcat, const int dv[3]) {
+    int nblk[3], HW = 0;
+    long total[3];
+    size_t poff[3], off = 0;
+    int max_nblk = 0;
+    TxTensor DV[3];
+    for (int b = 0; b < 3; ++b) {
+        DV[b] = t->T[dv[b]];
+        HW = DV[b].H * DV[b].W;
+        total[b] = (long)t->B * HEAD_C[b] * HW;
+        nblk[b] = (int)((total[b] + 255) / 256);
+        poff[b] = off; off += (size_t)nblk[b];
+        max_nblk = std::max(max_nblk, nblk[b]);
+    }
+    need_partial(t, off);
     t->ops.push_back([=](hipStream_t s) {
-        tx::HeadArgs a;
-        memset(&a, 0, sizeof a);
-        a.out = t->head_out[stage][b]; a.target = t->target[b]; a.fg = b == 2 ? t->fg : nullptr;
-        if (dcat >= 0) { const TxTensor D = t->T[dcat]; a.dextra = D.p + CAT_OFF[b]; a.de_cs = D.cs(); a.de_split = D.plane; }
-        a.dv = DV.p; a.dv_cs = DV.cs(); a.dv_split = DV.plane;
-        a.kind = HEAD_KIND[b]; a.C = C; a.HW = HW; a.total = total; a.inv_numel = (float)(1.0 / (double)total); a.partial = t->partial;
-        hipLaunchKernelGGL(tx::head_kernel, dim3(nblk), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(tx::loss_finish_kernel, dim3(1), dim3(256), 0, s, (const double *)t->partial, nblk, (double)total, t->loss + 3 * stage + b);
+        tx::Multi<tx::HeadArgs> h;
+        tx::Multi<tx::LossFinArgs> f;
+        memset(&h, 0, sizeof h); memset(&f, 0, sizeof f);
+        for (int b = 0; b < 3; ++b) {
+            tx::HeadArgs &a = h.a[b];
+            a.out = t->head_out[stage][b]; a.target = t->target[b]; a.fg = b == 2 ? t->fg : nullptr;
+            if (dcat >= 0) { const TxTensor D = t->T[dcat]; a.dextra = D.p + CAT_OFF[b]; a.de_cs = D.cs(); a.de_split = D.plane; }
+            a.dv = DV[b].p; a.dv_cs = DV[b].cs(); a.dv_split = DV[b].plane;
+            a.kind = HEAD_KIND[b]; a.C = HEAD_C[b]; a.HW = HW; a.total = total[b]; a.inv_numel = (float)(1.0 / (double)total[b]); a.partial = t->partial + poff[b];
+            f.a[b].partial = t->partial + poff[b]; f.a[b].nblocks = nblk[b]; f.a[b].numel = (double)total[b]; f.a[b].loss = t->loss + 3 * stage + b;
+        }
+        hipLaunchKernelGGL(tx::head_kernel, dim3(max_nblk, 3), dim3(256), 0, s, h);
+        hipLaunchKernelGGL(tx::loss_finish_kernel, dim3(3), dim3(256), 0, s, f);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
 }
 
 // fork: the side stream may start once everything issued so far on the step's stream has finished; join: the other way round
-int op_fork(pn_trainer *t) {
-    if (!t->two_streams || t->ops.size() == t->side_tail) return PN_OK;
+int op_fork(pn_trainer *t, int side = 0) {
+    if (!t->two_streams || (t->nside == 1 && t->ops.size() == t->side_tail)) return PN_OK;
     hipEvent_t ev;
     PN_HIP_CHECK(t->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     t->events.push_back(ev);
-    t->ops.push_back([t, ev](hipStream_t s) {
+    t->ops.push_back([t, ev, side](hipStream_t s) {
         PN_HIP_CHECK(t->ctx, hipEventRecord(ev, s));
-        PN_HIP_CHECK(t->ctx, hipStreamWaitEvent(t->side, ev, 0));
+        PN_HIP_CHECK(t->ctx, hipStreamWaitEvent(t->side[side], ev, 0));
         return (int)PN_OK;
     });
     return PN_OK;
 }
 int op_join(pn_trainer *t) {
     if (!t->two_streams) return PN_OK;
-    hipEvent_t ev;
-    PN_HIP_CHECK(t->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    t->events.push_back(ev);
-    t->ops.push_back([t, ev](hipStream_t s) {
-        PN_HIP_CHECK(t->ctx, hipEventRecord(ev, t->side));
-        PN_HIP_CHECK(t->ctx, hipStreamWaitEvent(s, ev, 0));
-        return (int)PN_OK;
-    });
+    for (int k = 0; k < t->nside; ++k) {
+        hipEvent_t ev;
+        PN_HIP_CHECK(t->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        t->events.push_back(ev);
+        t->ops.push_back([t, ev, k](hipStream_t s) {
+            PN_HIP_CHECK(t->ctx, hipEventRecord(ev, t->side[k]));
+            PN_HIP_CHECK(t->ctx, hipStreamWaitEvent(s, ev, 0));
+            return (int)PN_OK;
+        });
+    }
     return PN_OK;
 }
-// every op appended since `from` runs on the side stream
-void ops_to_side(pn_trainer *t, size_t from) {
+// every op appended since `from` runs on side stream `side`
+void ops_to_side(pn_trainer *t, size_t from, int side = 0) {
     if (!t->two_streams) return;
     for (size_t i = from; i < t->ops.size(); ++i) {
         auto f = t->ops[i];
-        t->ops[i] = [t, f](hipStream_t) { return f(t->side); };
+        t->ops[i] = [t, f, side](hipStream_t) { return f(t->side[side]); };
     }
     t->side_tail = t->ops.size();
 }
@@ -556,11 +573,13 @@ int op_wgrad(pn_trainer *t, int l, int dy) {
         return PN_OK;
     }
     if (L.b && !L.bn_follows) op_dbias(t, l, dy);      // (a bias in front of a BatchNorm: its gradient is identically zero and the flat gradient buffer already holds 0)
-    if (int rc = op_fork(t)) return rc;
+    const int side = t->two_streams ? t->next_side : 0;
+    t->next_side = (t->next_side + 1) % t->nside;
+    if (int rc = op_fork(t, side)) return rc;
     const size_t from = t->ops.size();
-    if (int rc = tx::plan_wgrad(t->ctx, t->B, X.H, X.W, X.p, X.plane, DY.p, DY.plane, L.cin, L.cout, L.ks, L.cat ? t->cat_k_map : nullptr, L.dw, &t->wg_partial, &t->wg_partial_floats, t->ops))
+    if (int rc = tx::plan_wgrad(t->ctx, t->B, X.H, X.W, X.p, X.plane, DY.p, DY.plane, L.cin, L.cout, L.ks, L.cat ? t->cat_k_map : nullptr, L.dw, &t->wg_partial[side], &t->wg_partial_floats, t->ops))
         return rc;
-    ops_to_side(t, from);
+    ops_to_side(t, from, side);
     return PN_OK;
 }
 
@@ -702,10 +721,9 @@ int build(pn_trainer *t) {
     auto stage_bwd = [&](int st, int dcat_in /* -1 for stage 2 */, int dx_plane, int *dx_out /* three tensors */) -> int {
         int rc2;
         int dy[3];
-        for (int b = 0; b < 3; ++b) {
+        for (int b = 0; b < 3; ++b)
             if ((rc2 = TT(H8, W8, 64, &dy[b]))) return rc2;
-            op_head(t, st, b, dcat_in, dy[b]);
-        }
+        op_heads(t, st, dcat_in, dy);
         for (int lv = 4; lv >= 0; --lv) {
             int dc[3];
             std::vector<BnBwdUse> bu;
@@ -795,7 +813,8 @@ int build(pn_trainer *t) {
     if ((rc = tx_alloc(t, (void **)&t->nchw_a, std::max<size_t>(t->nchw_elems, 1) * 4, true))) return rc;
     if ((rc = tx_alloc(t, (void **)&t->nchw_b, std::max<size_t>(t->nchw_elems, 1) * 4, true))) return rc;
     if (t->wg_partial_floats)
-        if ((rc = tx_alloc(t, (void **)&t->wg_partial, t->wg_partial_floats * 4, true))) return rc;
+        for (int k = 0; k < t->nside; ++k)
+            if ((rc = tx_alloc(t, (void **)&t->wg_partial[k], t->wg_partial_floats * 4, true))) return rc;
     if (!t->packs.empty()) {
         if ((rc = tx_alloc(t, (void **)&t->packs_dev, t->packs.size() * sizeof(tx::PackDesc), false))) return rc;
         PN_HIP_CHECK(ctx, hipMemcpy(t->packs_dev, t->packs.data(), t->packs.size() * sizeof(tx::PackDesc), hipMemcpyHostToDevice));
@@ -823,7 +842,8 @@ void pn_trainer_destroy(pn_trainer *t) {
     if (!t) return;
     for (void *p : t->allocs) (void)hipFree(p);
     for (hipEvent_t ev : t->events) (void)hipEventDestroy(ev);
-    if (t->side) (void)hipStreamDestroy(t->side);
+    for (int k = 0; k < 4; ++k)
+        if (t->side[k]) (void)hipStreamDestroy(t->side[k]);
     delete t;
 }
 
@@ -852,7 +872,10 @@ int pn_trainer_finalize(pn_trainer *t, float *flat_param_dev, float *flat_grad_d
     t->legacy_wgrad = e && !strcmp(e, "legacy");
     const char *e2 = getenv("POPNET_TRAINX_STREAMS");
     t->two_streams = !(e2 && atoi(e2) == 1) && !t->legacy_wgrad;
-    if (t->two_streams) PN_HIP_CHECK(ctx, hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    if (const char *e3 = getenv("POPNET_TRAINX_SIDES")) t->nside = std::max(1, std::min(4, atoi(e3)));
+    if (!t->two_streams) t->nside = 1;
+    if (t->two_streams)
+        for (int k = 0; k < t->nside; ++k) PN_HIP_CHECK(ctx, hipStreamCreateWithFlags(&t->side[k], hipStreamNonBlocking));
     if (int rc = build(t)) return rc;
     t->finalized = true;
     return PN_OK;

@@ -337,9 +337,11 @@ struct HeadArgs {
     int kind, C, HW; long total; float inv_numel;
     double *partial;
 };
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256) void head_kernel(Multi<HeadArgs> mm) {        // blockIdx.y = head (paf, heat, z)
     __shared__ double sh[4];
+    const HeadArgs &a = mm.a[blockIdx.y];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if ((long)blockIdx.x * 256 >= a.total) return;
     double e = 0.0;
     if (i < a.total) {
         const float o = a.out[i];
@@ -364,8 +366,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) a.partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ __launch_bounds__(256) void loss_finish_kernel(const double *__restrict__ partial, int nblocks, double numel, float *__restrict__ loss) {
+struct LossFinArgs { const double *partial; int nblocks; double numel; float *loss; };
+__global__ __launch_bounds__(256) void loss_finish_kernel(Multi<LossFinArgs> mm) {
     __shared__ double sh[4];
+    const double *partial = mm.a[blockIdx.x].partial;
+    const int nblocks = mm.a[blockIdx.x].nblocks;
+    const double numel = mm.a[blockIdx.x].numel;
+    float *loss = mm.a[blockIdx.x].loss;
     double s = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
