@@ -115,6 +115,7 @@ struct pn_net {
     int last_B = -1;
     bool x3 = false;                 // PN_PREC_BF16X3: tensors stored as [hi | lo] bf16 planes, read as [hi | lo | hi] against weights [W_hi | W_hi | W_lo]
     bool locked = false;             // pn_net_lock: descriptors frozen (a captured hipGraph reads them at replay time)
+    bool tickets_suspect = false;    // a forward of this net failed part-way: bb64_kernel's tile tickets may be non-zero -- re-zeroed before the next launch
     float *last_nchw[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<std::string, std::pair<int, std::pair<int, int>>> named;   // name -> (buf, (coff, C))
     double flops_per_frame = 0;
@@ -968,6 +969,14 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
             return pn_set_error(ctx, PN_ERR_STATE, "net is locked at batch %d (pn_net_lock): a forward with another batch size or other output buffers would rewrite descriptors a captured graph still reads", n->last_B);
         if (int rc = refresh_problems(n, B, stream)) return rc;
     }
+    // bb64_kernel's tile tickets are persistent device state that only a COMPLETED launch returns to zero; one net must not run two forwards at once (one
+    // stream per net: the engines keep it so), and after a forward that failed part-way the counters are re-zeroed here, in stream order, before anything
+    // can read them (a non-zero ticket would make every later launch -- graph replays included -- skip tiles silently)
+    if (n->tickets_suspect) {
+        for (auto &st : n->steps)
+            if (st.type == Step::BBLOCK && st.bb_tickets) PN_HIP_CHECK(ctx, hipMemsetAsync(st.bb_tickets, 0, 256, stream));
+        n->tickets_suspect = false;
+    }
     for (auto &st : n->steps) {
         int rc = PN_OK;
         pn_net::ProfRec *pr = nullptr;
@@ -1044,7 +1053,7 @@ int run_forward(pn_net *n, const float *x, int B, hipStream_t stream) {
         } else {
             rc = pn_launch_conv(ctx, st.launch, stream);
         }
-        if (rc) return rc;
+        if (rc) { n->tickets_suspect = true; return rc; }
         if (pr) PN_HIP_CHECK(ctx, hipEventRecord(pr->b, stream));
     }
     return PN_OK;
