@@ -874,8 +874,16 @@ int pn_trainer_finalize(pn_trainer *t, float *flat_param_dev, float *flat_grad_d
     t->two_streams = !(e2 && atoi(e2) == 1) && !t->legacy_wgrad;
     if (const char *e3 = getenv("POPNET_TRAINX_SIDES")) t->nside = std::max(1, std::min(4, atoi(e3)));
     if (!t->two_streams) t->nside = 1;
-    if (t->two_streams)
-        for (int k = 0; k < t->nside; ++k) PN_HIP_CHECK(ctx, hipStreamCreateWithFlags(&t->side[k], hipStreamNonBlocking));
+    if (t->two_streams) {
+        // LOWEST priority: the weight gradients fill what the step's own stream (the dependency chain that bounds the step) leaves idle, never the other way round
+        int lo = 0, hi = 0;
+        PN_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char *ep = getenv("POPNET_TRAINX_SIDE_PRIORITY");       // experiments: "default" = no priority
+        for (int k = 0; k < t->nside; ++k) {
+            if (ep && !strcmp(ep, "default")) PN_HIP_CHECK(ctx, hipStreamCreateWithFlags(&t->side[k], hipStreamNonBlocking));
+            else PN_HIP_CHECK(ctx, hipStreamCreateWithPriority(&t->side[k], hipStreamNonBlocking, lo));
+        }
+    }
     if (int rc = build(t)) return rc;
     t->finalized = true;
     return PN_OK;

@@ -122,10 +122,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (oy0 + r >= a.H) break;                     // wave-uniform: rows below the map hold dy = 0
-            bf8 A[2][2];
+        // Software-pipelined over the R * KK (row, tap) items of the strip: the fragments of item i + 1 are requested BEFORE the twelve MFMAs of item i are issued
+        // (one wave per SIMD: nothing else hides an LDS round trip; the compiler's own schedule read two fragments, waited, issued four MFMAs -- 31 % matrix-pipe use).
+        // sched_group_barrier pins the interleave: two reads, three MFMAs, four times per item.
+        const int rows = min(R, a.H - oy0);                // wave-uniform: rows below the map hold dy = 0 and are skipped
+        auto load_a = [&](int r, bf8 (&A)[2][2]) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -134,30 +135,49 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
                     const bf4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrA[mt] + r * ROWB + pl * 4096 + 2048));
                     A[mt][pl] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+        };
+        auto load_b = [&](int r, int tp, bf8 (&Bf)[2][2]) {
+            const int ky = tp / KS, kx = tp - ky * KS;
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    bf8 Bf[2][2];
+                for (int pl = 0; pl < 2; ++pl) {
+                    const bf4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + (r + ky) * ROWB + pl * 4096));
+                    const bf4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + (r + ky) * ROWB + pl * 4096 + 2048));
+                    Bf[nt][pl] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+        };
+        bf8 A[2][2][2], Bq[2][2][2];                       // [item parity]: current and next fragments
+        load_a(0, A[0]);
+        load_b(0, 0, Bq[0]);
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+        for (int r = 0; r < R; ++r) {
+            if (r >= rows) break;
 #pragma unroll
-                        for (int pl = 0; pl < 2; ++pl) {
-                            const bf4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + (r + ky) * ROWB + pl * 4096));
-                            const bf4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + (r + ky) * ROWB + pl * 4096 + 2048));
-                            Bf[nt][pl] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        }
-                    const int tp = ky * KS + kx;
+            for (int tp = 0; tp < KK; ++tp) {
+                const int cur = (r * KK + tp) & 1, nxt = cur ^ 1, ac = r & 1;
+                const bool more = tp + 1 < KK || r + 1 < rows;
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    if (tp + 1 < KK) load_b(r, tp + 1, Bq[nxt]);
+                    else { load_b(r + 1, 0, Bq[nxt]); load_a(r + 1, A[ac ^ 1]); }
+                }
+                // product-major: the three MFMAs into one accumulator tile sit four instructions apart (a dependent MFMA issued back to back waits out the first one's passes)
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][0], Bf[nt][0], acc[mt][nt][tp], 0, 0, 0);
-                            acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][1], Bf[nt][0], acc[mt][nt][tp], 0, 0, 0);
-                            acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][0], Bf[nt][1], acc[mt][nt][tp], 0, 0, 0);
-                        }
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ac][mt][pr == 1 ? 1 : 0], Bq[cur][nt][pr == 2 ? 1 : 0], acc[mt][nt][tp], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two LDS reads of the next item ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // ... then three MFMAs of this one
                 }
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     // partial[split][tap][co][ci]: a lane's 16 neighbours write 64 contiguous bytes
     float *part = a.partial + (size_t)blockIdx.x * KK * a.co_pad * a.ci_pad;
