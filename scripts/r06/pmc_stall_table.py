@@ -5,7 +5,7 @@ Columns (per kernel, whole run):
   wait%        SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   (share of resident-wave cycles spent waiting for any instruction's operands: vmcnt / lgkmcnt / exp)
   ldswait%     SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
   issue%       SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (a wave had an instruction in issue)
-  VALU/MFMA, LDS/MFMA, VMEM/MFMA   instruction-count ratios (per wave instruction)
+  VALU/MFMA, LDS/MFMA, VMEM/MFMA   instruction-count ratios (per wave instruction); SQ_INSTS_VALU counts the MFMAs too: other vector instructions per MFMA = VALU/MFMA - 1
   TA/MFMA      (TA_TA_BUSY_sum / 256 CUs) / (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs)
   tcpstall     TCP_PENDING_STALL_CYCLES_sum / TA_TA_BUSY_sum   (vector-memory requests stalled behind pending ones per busy texture-addresser cycle)
   ldsconf      SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"""
