@@ -25,6 +25,7 @@
 namespace tx {
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 struct WgArgs {
     const bf *x; int x_cs, x_split; unsigned x_zero;        // input tensor, byte offset of its zero page
@@ -194,6 +195,186 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
                 }
 }
 
+// ---- row-streaming form -------------------------------------------------------------------------------------------------------------------------
+// Same tiles, same fragments, same products as wgrad_kernel; what differs is how the images reach LDS.  wgrad_kernel fetches a 3-row strip (5 halo rows
+// of x, 3 rows of dy: 64 KB), waits, computes, and -- alone on its CU since the split-K went to one block per CU -- exposes that round trip once per strip
+// (36 % of wave cycles waiting).  Here a block walks a COLUMN STRIP top-down: rings of KS + D x rows and 1 + D dy rows (D = 2: the same 64 KB), per row ONE
+// group of four LDS-DMA instructions per wave for the row D ahead, ONE barrier, a counted `s_waitcnt vmcnt` (the D - 1 newer groups stay in flight) --
+// and no halo row is ever fetched twice.  A block owns `rows_per_block` consecutive rows of the flattened (image, column strip, row) space; where its range
+// crosses into the next column strip the rings are re-primed.
+struct WgsArgs {
+    const bf *x; int x_cs, x_split; unsigned x_zero;
+    const bf *dy; int dy_cs, dy_split; unsigned dy_zero;
+    int B, H, W;
+    int Wt, tiles_x, rows_total, rows_per_block;
+    int ncit, co_pad, ci_pad;
+    float *partial;
+};
+
+template <int KS, int D>
+__global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgsArgs a) {
+    typedef __attribute__((address_space(3))) bf4 lds4;
+    constexpr int KK = KS * KS, PAD = KS / 2, RING = 5;       // both rings hold RING rows: ring positions are compile-time in a body unrolled RING rows deep
+    static_assert(KS + D <= RING && 1 + D <= RING, "ring too small for the prefetch distance");
+    constexpr int ROWB = 2 * 32 * 128;
+    constexpr int XRING = RING * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [x ring][dy ring]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cot = blockIdx.y / a.ncit, cit = blockIdx.y - cot * a.ncit;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int pxl = 4 * g + q;
+    int addrA[2], addrB[KS][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int win = wm * 2 + mt, swz = (pxl >> 1) & 3;
+        addrA[mt] = XRING + pxl * 128 + ((((win ^ swz) << 1) | (p >> 1)) << 4) + ((p & 1) << 3);
+    }
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int win = wn * 2 + nt, hp = pxl + kx, swz = (hp >> 1) & 3;
+            addrB[kx][nt] = hp * 128 + ((((win ^ swz) << 1) | (p >> 1)) << 4) + ((p & 1) << 3);
+        }
+    f4 acc[2][2][KK];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int tp = 0; tp < KK; ++tp) acc[mt][nt][tp] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // every LDS byte a fragment read can touch holds finite data from the start: a tap-shifted read of the surplus pixel slots runs a few pixels past its row
+    // (multiplied by dy = 0 there -- but 0 x NaN is NaN, and LDS starts as whatever the previous kernel left)
+    for (int o = threadIdx.x * 16; o < 2 * XRING; o += 256 * 16) *reinterpret_cast<u32x4_t *>(smem + o) = u32x4_t{0u, 0u, 0u, 0u};
+
+    const int dpx = lane >> 3, dsp = lane & 7;
+    const int dma_px = wave * 8 + dpx;
+    const int dma_slot = (((dsp >> 1) ^ ((dma_px >> 1) & 3)) << 1) | (dsp & 1);
+    const unsigned lane_x = (unsigned)(((dma_px - PAD) * a.x_cs + ci0 + dma_slot * 8) * 2);
+    const unsigned lane_y = (unsigned)((dma_px * a.dy_cs + co0 + dma_slot * 8) * 2);
+    const unsigned rowx = (unsigned)(a.W * a.x_cs * 2), rowy = (unsigned)(a.W * a.dy_cs * 2);
+    const unsigned planex = (unsigned)(a.x_split * 2), planey = (unsigned)(a.dy_split * 2);
+    const unsigned dma_lds = (unsigned)__builtin_amdgcn_readfirstlane(wave * 1024);
+
+    int row = blockIdx.x * a.rows_per_block;
+    const int row_end = min(row + a.rows_per_block, a.rows_total);
+    while (row < row_end) {
+        // segment: rows [ya, yb) of column strip cs
+        const int cs = row / a.H, ya = row - cs * a.H;
+        const int yb = min(a.H, ya + (row_end - row));
+        const int nrows = yb - ya;
+        const int b = cs / a.tiles_x, tx_ = cs - b * a.tiles_x;
+        const int ox0 = tx_ * a.Wt, Wc = min(a.Wt, a.W - ox0);
+        const unsigned bx0 = (unsigned)(((long)b * a.H * a.W + ox0) * (long)a.x_cs * 2);      // image row 0 of the strip (row offsets added below, modulo 2^32)
+        const unsigned by0 = (unsigned)(((long)b * a.H * a.W + ox0) * (long)a.dy_cs * 2);
+        const bool okx = dma_px < Wc + 2 * PAD && (unsigned)(ox0 - PAD + dma_px) < (unsigned)a.W;
+        const bool oky = dma_px < Wc;
+        // x row number n of the segment = image row ya - PAD + n -> ring slot n % RING; dy row number n = image row ya + n -> slot n % RING
+        auto fetch_x = [&](int n, int slot) {
+            const int Y = ya - PAD + n;
+            const bool rowok = (unsigned)Y < (unsigned)a.H;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const unsigned off = (okx && rowok) ? bx0 + (unsigned)Y * rowx + (unsigned)pl * planex + lane_x : a.x_zero;
+                glds16(a.x, off, (unsigned)(slot * ROWB + pl * 4096) + dma_lds);
+            }
+        };
+        auto fetch_y = [&](int n, int slot) {
+            const int Y = ya + n;
+            const bool rowok = Y < yb;            // rows past the segment: zeros (their group is issued only to keep the vmcnt arithmetic uniform)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const unsigned off = (oky && rowok) ? by0 + (unsigned)Y * rowy + (unsigned)pl * planey + lane_y : a.dy_zero;
+                glds16(a.dy, off, (unsigned)(XRING + slot * ROWB + pl * 4096) + dma_lds);
+            }
+        };
+        __syncthreads();                          // the previous segment's fragment reads are done: the rings may be overwritten
+#pragma unroll
+        for (int n = 0; n < KS - 1; ++n) fetch_x(n, n % RING);
+#pragma unroll
+        for (int j = 0; j < D; ++j) { fetch_x(KS - 1 + j, (KS - 1 + j) % RING); fetch_y(j, j % RING); }
+        for (int k0 = 0; k0 < nrows; k0 += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {      // row k = k0 + u: k % RING == u
+                const int k = k0 + u;
+                if (k >= nrows) break;
+                // group k (x row number KS - 1 + k, dy row number k) has landed once at most D - 1 newer groups (4 instructions each) are outstanding
+                if (D == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (D == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __syncthreads();                  // ... for every wave's pieces; and every wave has finished row k - 1, whose slots group k + D overwrites
+                fetch_x(KS - 1 + k + D, (KS - 1 + u + D) % RING);
+                fetch_y(k + D, (u + D) % RING);
+                auto load_a = [&](bf8 (&A)[2][2]) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+                            const bf4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrA[mt] + u * ROWB + pl * 4096));
+                            const bf4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrA[mt] + u * ROWB + pl * 4096 + 2048));
+                            A[mt][pl] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                };
+                auto load_b = [&](int tp, bf8 (&Bf)[2][2]) {
+                    const int ky = tp / KS, kx = tp - ky * KS;
+                    const int xs = ((u + ky) % RING) * ROWB;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+                            const bf4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + xs + pl * 4096));
+                            const bf4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4 *)(smem + addrB[kx][nt] + xs + pl * 4096 + 2048));
+                            Bf[nt][pl] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                };
+                bf8 A[2][2], Bq[2][2][2];
+                load_a(A);
+                load_b(0, Bq[0]);
+#pragma unroll
+                for (int tp = 0; tp < KK; ++tp) {
+                    const int cur = tp & 1, nxt = cur ^ 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tp + 1 < KK) load_b(tp + 1, Bq[nxt]);
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][pr == 1 ? 1 : 0], Bq[cur][nt][pr == 2 ? 1 : 0], acc[mt][nt][tp], 0, 0, 0);
+                    if (tp + 1 < KK) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the D surplus groups of the segment's tail
+        row += nrows;
+    }
+    float *part = a.partial + (size_t)blockIdx.x * KK * a.co_pad * a.ci_pad;
+#pragma unroll
+    for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + wm * 32 + mt * 16 + 4 * g + i, ci = ci0 + wn * 32 + nt * 16 + (lane & 15);
+                    part[((size_t)tp * a.co_pad + co) * a.ci_pad + ci] = acc[mt][nt][tp][i];
+                }
+}
+
 // dw[co][ref ci][tap] = sum over the split slices, in a fixed order; k_map: this engine's input channel -> the reference's (nullptr = identity).
 // Block = 16 consecutive elements x 16 split lanes: lane l adds slices l, l + 16, ... (independent loads in flight), thread (element, lane 0) adds the
 // 16 lane sums in order.
@@ -259,6 +440,39 @@ inline int plan_wgrad(pn_ctx *ctx, int B, int H, int W, const bf *x, int x_plane
     *partial_floats = std::max(*partial_floats, (size_t)S * KK * a.co_pad * a.ci_pad);
     const size_t lds = (size_t)((R + ks - 1) + R) * 8192;
     const WgArgs a0 = a;
+    static const bool stream_form = !(getenv("POPNET_TRAINX_WG_STREAM") && atoi(getenv("POPNET_TRAINX_WG_STREAM")) == 0);
+    if (stream_form) {
+        constexpr int D = 2;
+        WgsArgs w;
+        memset(&w, 0, sizeof w);
+        w.x = a.x; w.x_cs = a.x_cs; w.x_split = a.x_split; w.x_zero = a.x_zero;
+        w.dy = a.dy; w.dy_cs = a.dy_cs; w.dy_split = a.dy_split; w.dy_zero = a.dy_zero;
+        w.B = B; w.H = H; w.W = W; w.Wt = a.Wt; w.tiles_x = a.tiles_x;
+        w.rows_total = B * a.tiles_x * H;
+        int Sr = std::max(1, std::min(w.rows_total, (per_cu_x2 * ctx->num_cus / 2 + pairs - 1) / pairs));
+        w.rows_per_block = (w.rows_total + Sr - 1) / Sr;
+        Sr = (w.rows_total + w.rows_per_block - 1) / w.rows_per_block;
+        w.ncit = a.ncit; w.co_pad = a.co_pad; w.ci_pad = a.ci_pad;
+        *partial_floats = std::max(*partial_floats, (size_t)Sr * KK * a.co_pad * a.ci_pad);
+        const size_t ldss = (size_t)(5 + 5) * 8192;            // two rings of five rows
+        ops.push_back([=](hipStream_t s) {
+            WgsArgs ww = w;
+            ww.partial = *partial;
+            if (ks == 3) {
+                static PnLdsAttr attr;
+                if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(wgrad_stream_kernel<3, 2>), ldss)) return rc;
+                hipLaunchKernelGGL((wgrad_stream_kernel<3, 2>), dim3(Sr, pairs), dim3(256), ldss, s, ww);
+            } else {
+                static PnLdsAttr attr;
+                if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(wgrad_stream_kernel<1, 2>), ldss)) return rc;
+                hipLaunchKernelGGL((wgrad_stream_kernel<1, 2>), dim3(Sr, pairs), dim3(256), ldss, s, ww);
+            }
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((size_t)KK * ww.co_pad * ww.ci_pad + 15) / 16)), dim3(256), 0, s, (const float *)ww.partial, Sr, KK, ww.co_pad, ww.ci_pad, Cout, Cin, k_map, dw);
+            PN_HIP_CHECK(ctx, hipGetLastError());
+            return (int)PN_OK;
+        });
+        return PN_OK;
+    }
     ops.push_back([=](hipStream_t s) {
         WgArgs a = a0;
         a.partial = *partial;                              // the host reads the pointer when the step launches (the buffer exists by then)
