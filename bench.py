@@ -321,7 +321,8 @@ def bench_env():
     a lab build that honours them is refused as well."""
     keep = ("GPU_MAX_HW_QUEUES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")
     env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("POPNET_") or k in keep}
-    forbidden = [k for k in env if k in ("POPNET_ABLATE_SKIP", "POPNET_X3_BF16_CONVS")]
+    # (POPNET_TRAINX_*: scheduling / cross-check switches of the planes training engine -- the bench times the defaults only)
+    forbidden = [k for k in env if k in ("POPNET_ABLATE_SKIP", "POPNET_X3_BF16_CONVS") or k.startswith("POPNET_TRAINX_")]
     if forbidden:
         raise SystemExit("bench.py: refusing to run with %s set (timing-only / result-changing experiment switches; unset them)" % ", ".join(forbidden))
     return env
