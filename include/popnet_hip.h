@@ -369,6 +369,10 @@ int pn_sgd_nesterov(pn_ctx *ctx, float *param_dev, const float *grad_dev, float 
 typedef struct pn_trainer pn_trainer;
 pn_trainer *pn_trainer_create(pn_ctx *ctx);
 void pn_trainer_destroy(pn_trainer *t);
+/* PN_PREC_BF16X3 (default): tensors as [hi | lo] bf16 planes, split-bf16 MFMA.  PN_PREC_F32: one fp32 plane per tensor, every product an exact fp32 FMA
+ * chain on v_mfma_f32_16x16x4_f32 (the generic fp32 inference kernel for forward / data gradient, a K = 4 pixel weight gradient): the parity mode.
+ * Call before pn_trainer_finalize. */
+int pn_trainer_set_precision(pn_trainer *t, int precision);
 int pn_trainer_set_param(pn_trainer *t, const char *name, size_t offset, size_t numel);
 int pn_trainer_set_stat(pn_trainer *t, const char *name, float *stat_dev);
 int pn_trainer_finalize(pn_trainer *t, float *flat_param_dev, float *flat_grad_dev, int B, int H, int W, float bn_momentum, float bn_eps);

@@ -126,6 +126,7 @@ _SIGNATURES = {
     "pn_sgd_nesterov": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _i, _f, _vp]),
     "pn_trainer_create": (_vp, [_vp]),
     "pn_trainer_destroy": (None, [_vp]),
+    "pn_trainer_set_precision": (_i, [_vp, _i]),
     "pn_trainer_set_param": (_i, [_vp, C.c_char_p, _sz, _sz]),
     "pn_trainer_set_stat": (_i, [_vp, C.c_char_p, _vp]),
     "pn_trainer_finalize": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f]),

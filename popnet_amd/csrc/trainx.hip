@@ -31,10 +31,13 @@ namespace {
 
 using tx::bf;
 
-struct TxTensor {
-    bf *p = nullptr;
+struct TxTensor {                     // [B][H][W][2 * plane] bf16 planes [hi | lo], or (fp32 engine) [B][H][W][plane] float: 4 bytes per channel either way
+    char *p = nullptr;
     int H = 0, W = 0, plane = 0;
-    int cs() const { return 2 * plane; }
+    bool f32 = false;
+    int cs() const { return f32 ? plane : 2 * plane; }      // channel stride in elements
+    int split() const { return f32 ? 0 : plane; }           // plane distance in elements (0: one fp32 plane)
+    char *at(int ch) const { return p + (size_t)ch * (f32 ? 4 : 2); }
 };
 
 struct TxBn {
@@ -74,6 +77,7 @@ struct pn_trainer {
     std::map<std::string, float *> stats;                        // running_mean / running_var device pointers
     bool finalized = false;
     bool legacy_wgrad = false;
+    bool f32 = false;                // precision "fp32": one fp32 plane per tensor, the generic fp32 convolution kernel, K = 4 weight gradient
     std::vector<void *> allocs;
     std::vector<TxTensor> T;
     std::vector<TxBn> bns;
@@ -121,8 +125,8 @@ int tx_alloc(pn_trainer *t, void **p, size_t bytes, bool zero) {
 
 int new_tensor(pn_trainer *t, int H, int W, int plane, int *id) {
     TxTensor x;
-    x.H = H; x.W = W; x.plane = plane;
-    const size_t bytes = (size_t)t->B * H * W * 2 * plane * 2 + 2048;      // + zero page: the halo DMA's padding source
+    x.H = H; x.W = W; x.plane = plane; x.f32 = t->f32;
+    const size_t bytes = (size_t)t->B * H * W * plane * 4 + 2048;          // (two bf16 planes or one fp32 plane) + zero page: the halo DMA's padding source
     if (bytes >= ((size_t)1 << 32)) return pn_set_error(t->ctx, PN_ERR_UNSUPPORTED, "pn_trainer: a %dx%dx%d tensor at batch %d exceeds the 4 GiB the kernels' 32-bit offsets address", H, W, plane, t->B);
     if (int rc = tx_alloc(t, (void **)&x.p, bytes, true)) return rc;
     t->T.push_back(x);
@@ -187,11 +191,12 @@ int ensure_pack(pn_trainer *t, const PlannedConv &pc, bf **dst_out) {
     const int KK = pc.ks * pc.ks, ksteps = pc.cin_chunks * KK * 2;
     const bool k4 = pc.g.kern == 4;
     const size_t real_groups = k4 ? (size_t)(pc.cout_pad / 128) * (ksteps + 3) * 8 * 64 : (size_t)(pc.cout_pad / 16) * ksteps * 64;
-    const size_t bytes = real_groups * 16 + (k4 ? 0 : 5 * 1024);          // + spare fragments: the weight queue prefetches up to 5 k-steps ahead
+    const size_t gbytes = t->f32 ? 32 : 16;                               // one lane's share of a fragment: 8 values
+    const size_t bytes = real_groups * gbytes + (k4 ? 0 : 5 * 64 * gbytes);          // + spare fragments: the weight queue prefetches up to 5 k-steps ahead
     if (int rc = tx_alloc(t, (void **)&slot, bytes, true)) return rc;
     tx::PackDesc d;
     memset(&d, 0, sizeof d);
-    d.w = L.w; d.dst = slot; d.Cout = L.cout; d.Cin = L.cin; d.ks = pc.ks;
+    d.w = L.w; d.dst = slot; d.f32 = t->f32 ? 1 : 0; d.Cout = L.cout; d.Cin = L.cin; d.ks = pc.ks;
     d.transpose = pc.u.dgrad ? 1 : 0; d.conv4 = k4 ? 1 : 0;
     d.CT = pc.g.kern == 3 ? 2 : pn_cfg_ct(pc.g.cfg);
     d.rows_valid = pc.rows; d.kplane = pc.kplane; d.ksteps = ksteps;
@@ -231,12 +236,13 @@ int add_conv_group(pn_trainer *t, const std::vector<ConvUse> &uses) {
         pc.rows = u.dgrad ? t->T[L.x].plane : L.cout;
         pc.kplane = in.plane;
         if (pc.kplane % 64) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "pn_trainer: %s: input plane %d is not a multiple of 64", L.name.c_str(), pc.kplane);
-        pc.cin_chunks = 3 * pc.kplane / 64;
+        pc.cin_chunks = (t->f32 ? 1 : 3) * pc.kplane / 64;
         pc.g = ConvGeom();
         const int wc_min = (wide[L.ks] && pc.rows > 32) ? 4 : 0;
-        pn_plan_conv_kernel(PN_PREC_BF16, t->B, ctx->num_cus, in.H, in.W, pc.rows, L.ks, 1, pc.cin_chunks, wc_min, 0, k4 ? 1 : 0, pc.g);
+        const int prec = t->f32 ? PN_PREC_F32 : PN_PREC_BF16;
+        pn_plan_conv_kernel(prec, t->B, ctx->num_cus, in.H, in.W, pc.rows, L.ks, 1, pc.cin_chunks, wc_min, 0, k4 ? 1 : 0, pc.g);
         const char *why = "";
-        if (int rc = pn_plan_conv_tiles(PN_PREC_BF16, in.H, in.W, L.ks, 1, pc.g, &why)) return pn_set_error(ctx, rc, "pn_trainer: %s: %s", L.name.c_str(), why);
+        if (int rc = pn_plan_conv_tiles(prec, in.H, in.W, L.ks, 1, pc.g, &why)) return pn_set_error(ctx, rc, "pn_trainer: %s: %s", L.name.c_str(), why);
         if (pc.g.kern == 0 && L.ks == 1 && pc.g.pitch == 16) pc.g.pitch = 32;      // the generic 1x1 kernel is not instantiated for the 16-pixel pitch class (a wider LDS row is always valid)
         pc.BC = pc.g.kern == 4 ? 128 : (pc.g.kern == 3 ? pc.g.wc * 32 : pn_cfg_couts(pc.g.cfg));
         pc.cout_pad = (pc.rows + pc.BC - 1) / pc.BC * pc.BC;
@@ -277,10 +283,10 @@ int add_conv_group(pn_trainer *t, const std::vector<ConvUse> &uses) {
             } else P.bias = t->zero_bias;
             P.B = t->B; P.H = in.H; P.W = in.W; P.Ho = in.H; P.Wo = in.W;
             P.cin_chunks = pc.cin_chunks; P.in_cs = in.cs(); P.in_coff = 0;
-            P.in_wrap = 2 * (in.plane / 64);
+            P.in_wrap = t->f32 ? (1 << 20) : 2 * (in.plane / 64);
             P.cout = pc.rows;
-            if (pc.u.out >= 0) { const TxTensor &o = t->T[pc.u.out]; P.out = o.p; P.out_cs = o.cs(); P.out_coff = pc.u.out_coff; P.split = o.plane; }
-            if (pc.u.res >= 0) { const TxTensor &r = t->T[pc.u.res]; P.res = r.p; P.res_cs = r.cs(); P.res_coff = 0; P.res_split = r.plane; }
+            if (pc.u.out >= 0) { const TxTensor &o = t->T[pc.u.out]; P.out = o.p; P.out_cs = o.cs(); P.out_coff = pc.u.out_coff; P.split = o.split(); }
+            if (pc.u.res >= 0) { const TxTensor &r = t->T[pc.u.res]; P.res = r.p; P.res_cs = r.cs(); P.res_coff = 0; P.res_split = r.split(); }
             P.out_nchw = pc.u.out_nchw;
             P.act = pc.u.act;
             P.yolo_naf = 50;
@@ -292,23 +298,23 @@ int add_conv_group(pn_trainer *t, const std::vector<ConvUse> &uses) {
             if (pc.g.kern == 4) P.nblocks = ((t->B * P.tiles_per_img + 1) / 2) * P.cout_blocks;
             P.ksteps = pc.cin_chunks * pc.ks * pc.ks * 2;
             P.ks = pc.ks;
-            P.lds_buf_bytes = (int)pn_conv_lds_bytes(PN_PREC_BF16, pc.ks, 1, pc.g.pitch, pc.g.R);
+            P.lds_buf_bytes = (int)pn_conv_lds_bytes(t->f32 ? PN_PREC_F32 : PN_PREC_BF16, pc.ks, 1, pc.g.pitch, pc.g.R);
             P.lds_two = (pc.cin_chunks > 1 && 2 * (size_t)P.lds_buf_bytes <= 160 * 1024) ? 1 : 0;
-            P.in_zero_off = (unsigned)((size_t)t->B * in.H * in.W * in.cs() * 2);
+            P.in_zero_off = (unsigned)((size_t)t->B * in.H * in.W * in.plane * 4);
             if (P.lds_two) two_bufs = true;
             max_blocks = std::max(max_blocks, P.nblocks);
             probs.push_back(P);
-            t->flops_conv += 2.0 * 3.0 * (double)t->B * in.H * in.W * pc.rows * pc.kplane * pc.ks * pc.ks;
+            t->flops_conv += 2.0 * (t->f32 ? 1.0 : 3.0) * (double)t->B * in.H * in.W * pc.rows * pc.kplane * pc.ks * pc.ks;
         }
         ConvProblem *dev = nullptr;
         if (int rc = tx_alloc(t, (void **)&dev, probs.size() * sizeof(ConvProblem), false)) return rc;
         PN_HIP_CHECK(ctx, hipMemcpy(dev, probs.data(), probs.size() * sizeof(ConvProblem), hipMemcpyHostToDevice));
         ConvLaunch cl;
-        cl.prec = PN_PREC_BF16; cl.ks = a.ks; cl.stride = 1; cl.pitch = a.g.pitch; cl.cfg = a.g.cfg;
+        cl.prec = t->f32 ? PN_PREC_F32 : PN_PREC_BF16; cl.ks = a.ks; cl.stride = 1; cl.pitch = a.g.pitch; cl.cfg = a.g.cfg;
         cl.kern = a.g.kern; cl.wc = a.g.wc; cl.wp = a.g.wp; cl.nbuf = a.g.nbuf; cl.pt = a.g.pt; cl.rpg = a.g.rpg;
         cl.tail = 0; cl.mix = 0;
         cl.nprob = (int)probs.size(); cl.max_blocks = max_blocks;
-        cl.lds_bytes = pn_conv_lds_bytes(PN_PREC_BF16, a.ks, 1, a.g.pitch, a.g.R) * (two_bufs ? 2 : 1);
+        cl.lds_bytes = pn_conv_lds_bytes(cl.prec, a.ks, 1, a.g.pitch, a.g.R) * (two_bufs ? 2 : 1);
         if (a.g.kern == 3) cl.lds_bytes = pn_conv3_lds_bytes(a.ks, a.g.wp, a.g.nbuf, a.g.rpg);
         if (a.g.kern == 4) cl.lds_bytes = 0;
         cl.probs_dev = dev;
@@ -357,19 +363,21 @@ void op_bn_fwd(pn_trainer *t, std::vector<BnUse> uses) {
             const TxBn &b = t->bns[uses[i].bn];
             const TxTensor X = t->T[uses[i].x], Y = t->T[uses[i].y];
             tx::RedArgs &ri = r.a[i];
-            ri.x = X.p; ri.x_cs = X.cs(); ri.x_split = X.plane; ri.C = g[i].C; ri.npix = g[i].npix; ri.ppb = g[i].ppb; ri.nblk = g[i].nblk; ri.partial = t->partial + g[i].poff;
+            ri.x = X.p; ri.x_cs = X.cs(); ri.x_split = X.split(); ri.C = g[i].C; ri.npix = g[i].npix; ri.ppb = g[i].ppb; ri.nblk = g[i].nblk; ri.partial = t->partial + g[i].poff;
             tx::BnFinArgs &fi = f.a[i];
             fi.partial = t->partial + g[i].poff; fi.nblk = g[i].nblk; fi.C = g[i].C; fi.n = (double)g[i].npix; fi.gamma = b.gamma; fi.beta = b.beta;
             fi.mean = b.mean; fi.invstd = b.invstd; fi.scale = b.scale; fi.shift = b.shift; fi.running_mean = b.rm; fi.running_var = b.rv;
             fi.momentum = t->momentum; fi.eps = t->eps;
             tx::BnApplyArgs &ai = a.a[i];
-            ai.x = X.p; ai.x_cs = X.cs(); ai.x_split = X.plane;
-            if (uses[i].res >= 0) { const TxTensor R = t->T[uses[i].res]; ai.res = R.p; ai.res_cs = R.cs(); ai.res_split = R.plane; }
-            ai.y = Y.p; ai.y_cs = Y.cs(); ai.y_split = Y.plane; ai.scale = b.scale; ai.shift = b.shift; ai.act = uses[i].act; ai.C = g[i].C; ai.npix = g[i].npix;
+            ai.x = X.p; ai.x_cs = X.cs(); ai.x_split = X.split();
+            if (uses[i].res >= 0) { const TxTensor R = t->T[uses[i].res]; ai.res = R.p; ai.res_cs = R.cs(); ai.res_split = R.split(); }
+            ai.y = Y.p; ai.y_cs = Y.cs(); ai.y_split = Y.split(); ai.scale = b.scale; ai.shift = b.shift; ai.act = uses[i].act; ai.C = g[i].C; ai.npix = g[i].npix;
         }
-        hipLaunchKernelGGL(tx::reduce_kernel<0>, dim3(max_nblk, n), dim3(256), 0, s, r);
+        if (t->f32) hipLaunchKernelGGL((tx::reduce_kernel<0, float>), dim3(max_nblk, n), dim3(256), 0, s, r);
+        else hipLaunchKernelGGL((tx::reduce_kernel<0, bf>), dim3(max_nblk, n), dim3(256), 0, s, r);
         hipLaunchKernelGGL(tx::bn_finish_kernel, dim3((max_c + 3) / 4, n), dim3(256), 0, s, f);
-        hipLaunchKernelGGL(tx::bn_apply_kernel, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
+        if (t->f32) hipLaunchKernelGGL(tx::bn_apply_kernel<float>, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(tx::bn_apply_kernel<bf>, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
@@ -400,24 +408,26 @@ void op_bn_bwd(pn_trainer *t, std::vector<BnBwdUse> uses) {
             const TxBn &b = t->bns[u.bn];
             const TxTensor X = t->T[u.x], DY = t->T[u.dy], Y = t->T[u.y], DX = t->T[u.dx];
             // the activation's sign: from the stored output when a residual went into it, else recomputed from x (one tensor less to read)
-            const bf *ysrc = (u.act && u.has_res) ? Y.p : nullptr;
+            const char *ysrc = (u.act && u.has_res) ? Y.p : nullptr;
             tx::RedArgs &ri = r.a[i];
-            ri.x = X.p; ri.x_cs = X.cs(); ri.x_split = X.plane; ri.dy = DY.p; ri.dy_cs = DY.cs(); ri.dy_split = DY.plane;
+            ri.x = X.p; ri.x_cs = X.cs(); ri.x_split = X.split(); ri.dy = DY.p; ri.dy_cs = DY.cs(); ri.dy_split = DY.split();
             ri.y = ysrc; ri.y_cs = Y.cs(); ri.mean = b.mean; ri.invstd = b.invstd; ri.scale = b.scale; ri.shift = b.shift; ri.act = u.act;
             ri.C = g[i].C; ri.npix = g[i].npix; ri.ppb = g[i].ppb; ri.nblk = g[i].nblk; ri.partial = t->partial + g[i].poff;
             tx::BnBwdFinArgs &fi = f.a[i];
             fi.partial = t->partial + g[i].poff; fi.nblk = g[i].nblk; fi.C = g[i].C; fi.n = (double)g[i].npix; fi.gamma = b.gamma; fi.invstd = b.invstd;
             fi.dgamma = b.dgamma; fi.dbeta = b.dbeta; fi.k1 = b.k1; fi.k2 = b.k2; fi.k3 = b.k3;
             tx::BnBwdApplyArgs &ai = a.a[i];
-            ai.x = X.p; ai.x_cs = X.cs(); ai.x_split = X.plane; ai.dy = DY.p; ai.dy_cs = DY.cs(); ai.dy_split = DY.plane;
+            ai.x = X.p; ai.x_cs = X.cs(); ai.x_split = X.split(); ai.dy = DY.p; ai.dy_cs = DY.cs(); ai.dy_split = DY.split();
             ai.y = ysrc; ai.y_cs = Y.cs(); ai.mean = b.mean; ai.invstd = b.invstd; ai.k1 = b.k1; ai.k2 = b.k2; ai.k3 = b.k3; ai.scale = b.scale; ai.shift = b.shift;
-            ai.dx = DX.p; ai.dx_cs = DX.cs(); ai.dx_split = DX.plane;
-            if (u.dres >= 0) { const TxTensor R = t->T[u.dres]; ai.dres = R.p; ai.dres_cs = R.cs(); ai.dres_split = R.plane; }
+            ai.dx = DX.p; ai.dx_cs = DX.cs(); ai.dx_split = DX.split();
+            if (u.dres >= 0) { const TxTensor R = t->T[u.dres]; ai.dres = R.p; ai.dres_cs = R.cs(); ai.dres_split = R.split(); }
             ai.act = u.act; ai.C = g[i].C; ai.npix = g[i].npix;
         }
-        hipLaunchKernelGGL(tx::reduce_kernel<1>, dim3(max_nblk, n), dim3(256), 0, s, r);
+        if (t->f32) hipLaunchKernelGGL((tx::reduce_kernel<1, float>), dim3(max_nblk, n), dim3(256), 0, s, r);
+        else hipLaunchKernelGGL((tx::reduce_kernel<1, bf>), dim3(max_nblk, n), dim3(256), 0, s, r);
         hipLaunchKernelGGL(tx::bn_bwd_finish_kernel, dim3((max_c + 3) / 4, n), dim3(256), 0, s, f);
-        hipLaunchKernelGGL(tx::bn_bwd_apply_kernel, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
+        if (t->f32) hipLaunchKernelGGL(tx::bn_bwd_apply_kernel<float>, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(tx::bn_bwd_apply_kernel<bf>, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
@@ -439,8 +449,9 @@ void op_dbias(pn_trainer *t, int l, int dy) {
         tx::Multi<tx::RedArgs> r;
         memset(&r, 0, sizeof r);
         tx::RedArgs &ri = r.a[0];
-        ri.x = DY.p; ri.x_cs = DY.cs(); ri.x_split = DY.plane; ri.C = C; ri.npix = npix; ri.ppb = ppb; ri.nblk = nblk; ri.partial = t->partial;
-        hipLaunchKernelGGL(tx::reduce_kernel<2>, dim3(nblk, 1), dim3(256), 0, s, r);
+        ri.x = DY.p; ri.x_cs = DY.cs(); ri.x_split = DY.split(); ri.C = C; ri.npix = npix; ri.ppb = ppb; ri.nblk = nblk; ri.partial = t->partial;
+        if (t->f32) hipLaunchKernelGGL((tx::reduce_kernel<2, float>), dim3(nblk, 1), dim3(256), 0, s, r);
+        else hipLaunchKernelGGL((tx::reduce_kernel<2, bf>), dim3(nblk, 1), dim3(256), 0, s, r);
         hipLaunchKernelGGL(tx::sum_finish_kernel, dim3((L.cout + 3) / 4), dim3(256), 0, s, (const double *)t->partial, nblk, C, L.cout, L.db);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
@@ -453,10 +464,11 @@ void op_add(pn_trainer *t, std::vector<std::array<int, 2>> ins /* (tensor, chann
     tx::AddArgs a;
     memset(&a, 0, sizeof a);
     a.n = (int)ins.size();
-    for (int i = 0; i < a.n; ++i) { const TxTensor X = t->T[ins[i][0]]; a.in[i] = X.p + ins[i][1]; a.cs[i] = X.cs(); a.split[i] = X.plane; }
-    a.out = O.p; a.out_cs = O.cs(); a.out_split = O.plane; a.C = C; a.npix = npix;
+    for (int i = 0; i < a.n; ++i) { const TxTensor X = t->T[ins[i][0]]; a.in[i] = X.at(ins[i][1]); a.cs[i] = X.cs(); a.split[i] = X.split(); }
+    a.out = O.p; a.out_cs = O.cs(); a.out_split = O.split(); a.C = C; a.npix = npix;
     t->ops.push_back([=](hipStream_t s) {
-        hipLaunchKernelGGL(tx::add_kernel, dim3(grid_for(npix * (C / 8), t->ctx->num_cus)), dim3(256), 0, s, a);
+        if (t->f32) hipLaunchKernelGGL(tx::add_kernel<float>, dim3(grid_for(npix * (C / 8), t->ctx->num_cus)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(tx::add_kernel<bf>, dim3(grid_for(npix * (C / 8), t->ctx->num_cus)), dim3(256), 0, s, a);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
@@ -465,7 +477,7 @@ void op_add(pn_trainer *t, std::vector<std::array<int, 2>> ins /* (tensor, chann
 void op_pool_fwd(pn_trainer *t, int x, int y, int out_coff) {
     const TxTensor X = t->T[x], Y = t->T[y];
     t->ops.push_back([=](hipStream_t s) {
-        return pn_launch_pool(t->ctx, PN_PREC_BF16, 0, X.p, Y.p, t->B, X.H, X.W, X.plane, X.cs(), Y.cs(), out_coff, X.plane, Y.plane, s);
+        return pn_launch_pool(t->ctx, t->f32 ? PN_PREC_F32 : PN_PREC_BF16, 0, X.p, Y.p, t->B, X.H, X.W, X.plane, X.cs(), Y.cs(), out_coff, X.split(), Y.split(), s);
     });
 }
 
@@ -473,8 +485,10 @@ void op_pool_bwd(pn_trainer *t, int dy, int dx) {
     const TxTensor DY = t->T[dy], DX = t->T[dx];
     t->ops.push_back([=](hipStream_t s) {
         const long items = (long)t->B * DX.H * DX.W * (DX.plane / 8);
-        hipLaunchKernelGGL(tx::avgpool_bwd_kernel, dim3(grid_for(items, t->ctx->num_cus)), dim3(256), 0, s, (const bf *)DY.p, DY.cs(), DY.plane, DX.p, DX.cs(), DX.plane,
-                           t->B, DX.H, DX.W, DY.H, DY.W, DX.plane);
+        if (t->f32) hipLaunchKernelGGL(tx::avgpool_bwd_kernel<float>, dim3(grid_for(items, t->ctx->num_cus)), dim3(256), 0, s, (const float *)DY.p, DY.cs(), 0, (float *)DX.p, DX.cs(), 0,
+                                       t->B, DX.H, DX.W, DY.H, DY.W, DX.plane);
+        else hipLaunchKernelGGL(tx::avgpool_bwd_kernel<bf>, dim3(grid_for(items, t->ctx->num_cus)), dim3(256), 0, s, (const bf *)DY.p, DY.cs(), DY.plane, (bf *)DX.p, DX.cs(), DX.plane,
+                                t->B, DX.H, DX.W, DY.H, DY.W, DX.plane);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
     });
@@ -503,12 +517,13 @@ void op_heads(pn_trainer *t, int stage, int dcat, const int dv[3]) {
         for (int b = 0; b < 3; ++b) {
             tx::HeadArgs &a = h.a[b];
             a.out = t->head_out[stage][b]; a.target = t->target[b]; a.fg = b == 2 ? t->fg : nullptr;
-            if (dcat >= 0) { const TxTensor D = t->T[dcat]; a.dextra = D.p + CAT_OFF[b]; a.de_cs = D.cs(); a.de_split = D.plane; }
-            a.dv = DV[b].p; a.dv_cs = DV[b].cs(); a.dv_split = DV[b].plane;
+            if (dcat >= 0) { const TxTensor D = t->T[dcat]; a.dextra = D.at(CAT_OFF[b]); a.de_cs = D.cs(); a.de_split = D.split(); }
+            a.dv = DV[b].p; a.dv_cs = DV[b].cs(); a.dv_split = DV[b].split();
             a.kind = HEAD_KIND[b]; a.C = HEAD_C[b]; a.HW = HW; a.total = total[b]; a.inv_numel = (float)(1.0 / (double)total[b]); a.partial = t->partial + poff[b];
             f.a[b].partial = t->partial + poff[b]; f.a[b].nblocks = nblk[b]; f.a[b].numel = (double)total[b]; f.a[b].loss = t->loss + 3 * stage + b;
         }
-        hipLaunchKernelGGL(tx::head_kernel, dim3(max_nblk, 3), dim3(256), 0, s, h);
+        if (t->f32) hipLaunchKernelGGL(tx::head_kernel<float>, dim3(max_nblk, 3), dim3(256), 0, s, h);
+        else hipLaunchKernelGGL(tx::head_kernel<bf>, dim3(max_nblk, 3), dim3(256), 0, s, h);
         hipLaunchKernelGGL(tx::loss_finish_kernel, dim3(3), dim3(256), 0, s, f);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
@@ -563,10 +578,14 @@ int op_wgrad(pn_trainer *t, int l, int dy) {
         t->ops.push_back([=](hipStream_t s) {
             const TxLayer &LL = t->layers[l];
             const int HW = X.H * X.W;
-            hipLaunchKernelGGL(tx::planes_to_nchw_kernel, dim3((HW + 63) / 64, (LL.cin + 63) / 64, t->B), dim3(256), 0, s, (const bf *)X.p, X.cs(), X.plane, t->nchw_a, LL.cin, HW,
-                               LL.cat ? (const int *)t->cat_ref_map : (const int *)nullptr);
-            hipLaunchKernelGGL(tx::planes_to_nchw_kernel, dim3((HW + 63) / 64, (LL.cout + 63) / 64, t->B), dim3(256), 0, s, (const bf *)DY.p, DY.cs(), DY.plane, t->nchw_b, LL.cout, HW,
-                               (const int *)nullptr);
+            const int *cmap = LL.cat ? (const int *)t->cat_ref_map : (const int *)nullptr;
+            if (t->f32) {
+                hipLaunchKernelGGL(tx::planes_to_nchw_kernel<float>, dim3((HW + 63) / 64, (LL.cin + 63) / 64, t->B), dim3(256), 0, s, (const float *)X.p, X.cs(), 0, t->nchw_a, LL.cin, HW, cmap);
+                hipLaunchKernelGGL(tx::planes_to_nchw_kernel<float>, dim3((HW + 63) / 64, (LL.cout + 63) / 64, t->B), dim3(256), 0, s, (const float *)DY.p, DY.cs(), 0, t->nchw_b, LL.cout, HW, (const int *)nullptr);
+            } else {
+                hipLaunchKernelGGL(tx::planes_to_nchw_kernel<bf>, dim3((HW + 63) / 64, (LL.cin + 63) / 64, t->B), dim3(256), 0, s, (const bf *)X.p, X.cs(), X.plane, t->nchw_a, LL.cin, HW, cmap);
+                hipLaunchKernelGGL(tx::planes_to_nchw_kernel<bf>, dim3((HW + 63) / 64, (LL.cout + 63) / 64, t->B), dim3(256), 0, s, (const bf *)DY.p, DY.cs(), DY.plane, t->nchw_b, LL.cout, HW, (const int *)nullptr);
+            }
             PN_HIP_CHECK(t->ctx, hipGetLastError());
             return pn_conv2d_wgrad(t->ctx, t->nchw_a, t->nchw_b, LL.dw, LL.db, t->B, LL.cin, X.H, X.W, LL.cout, LL.ks, 1, LL.ks / 2, (void *)s);
         });
@@ -577,7 +596,12 @@ int op_wgrad(pn_trainer *t, int l, int dy) {
     t->next_side = (t->next_side + 1) % t->nside;
     if (int rc = op_fork(t, side)) return rc;
     const size_t from = t->ops.size();
-    if (int rc = tx::plan_wgrad(t->ctx, t->B, X.H, X.W, X.p, X.plane, DY.p, DY.plane, L.cin, L.cout, L.ks, L.cat ? t->cat_k_map : nullptr, L.dw, &t->wg_partial[side], &t->wg_partial_floats, t->ops))
+    if (t->f32) {
+        if (int rc = tx::plan_wgrad_f32(t->ctx, t->B, X.H, X.W, (const float *)X.p, X.plane, (const float *)DY.p, DY.plane, L.cin, L.cout, L.ks, L.cat ? t->cat_k_map : nullptr, L.dw,
+                                        &t->wg_partial[side], &t->wg_partial_floats, t->ops))
+            return rc;
+    } else if (int rc = tx::plan_wgrad(t->ctx, t->B, X.H, X.W, (const bf *)X.p, X.plane, (const bf *)DY.p, DY.plane, L.cin, L.cout, L.ks, L.cat ? t->cat_k_map : nullptr, L.dw,
+                                       &t->wg_partial[side], &t->wg_partial_floats, t->ops))
         return rc;
     ops_to_side(t, from, side);
     return PN_OK;
@@ -627,7 +651,8 @@ int build(pn_trainer *t) {
         t->ops.push_back([=](hipStream_t s) {
             if (int r = pn_conv2d_forward(t->ctx, t->img, w_stem, nullptr, t->nchw_a, B, 1, H, W, 64, 7, 2, 3, 0, (void *)s)) return r;
             const int HW = H2 * W2;
-            hipLaunchKernelGGL(tx::nchw_to_planes_kernel, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)t->nchw_a, c0.p, 64, HW, c0.cs(), c0.plane);
+            if (t->f32) hipLaunchKernelGGL(tx::nchw_to_planes_kernel<float>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)t->nchw_a, (float *)c0.p, 64, HW, c0.cs(), 0);
+            else hipLaunchKernelGGL(tx::nchw_to_planes_kernel<bf>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)t->nchw_a, (bf *)c0.p, 64, HW, c0.cs(), c0.plane);
             PN_HIP_CHECK(t->ctx, hipGetLastError());
             return (int)PN_OK;
         });
@@ -801,7 +826,8 @@ int build(pn_trainer *t) {
         const TxTensor d0 = t->T[dC0];
         t->ops.push_back([=](hipStream_t s) {
             const int HW = H2 * W2;
-            hipLaunchKernelGGL(tx::planes_to_nchw_kernel, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const bf *)d0.p, d0.cs(), d0.plane, t->nchw_b, 64, HW, (const int *)nullptr);
+            if (t->f32) hipLaunchKernelGGL(tx::planes_to_nchw_kernel<float>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)d0.p, d0.cs(), 0, t->nchw_b, 64, HW, (const int *)nullptr);
+            else hipLaunchKernelGGL(tx::planes_to_nchw_kernel<bf>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const bf *)d0.p, d0.cs(), d0.plane, t->nchw_b, 64, HW, (const int *)nullptr);
             PN_HIP_CHECK(t->ctx, hipGetLastError());
             return pn_conv2d_wgrad(t->ctx, t->img, t->nchw_b, dw_stem, nullptr, B, 1, H, W, 64, 7, 2, 3, (void *)s);
         });
@@ -858,6 +884,14 @@ int pn_trainer_set_stat(pn_trainer *t, const char *name, float *stat_dev) {
     if (!t || !name || !stat_dev) return PN_ERR_INVALID;
     if (t->finalized) return pn_set_error(t->ctx, PN_ERR_STATE, "pn_trainer: already finalized");
     t->stats[name] = stat_dev;
+    return PN_OK;
+}
+
+int pn_trainer_set_precision(pn_trainer *t, int precision) {
+    if (!t) return PN_ERR_INVALID;
+    if (t->finalized) return pn_set_error(t->ctx, PN_ERR_STATE, "pn_trainer: already finalized");
+    if (precision != PN_PREC_F32 && precision != PN_PREC_BF16X3) return pn_set_error(t->ctx, PN_ERR_INVALID, "pn_trainer_set_precision: PN_PREC_F32 or PN_PREC_BF16X3");
+    t->f32 = precision == PN_PREC_F32;
     return PN_OK;
 }
 

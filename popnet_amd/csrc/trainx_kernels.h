@@ -41,6 +41,31 @@ __device__ __forceinline__ void st8x(bf *p, int split, const float (&v)[8]) {
     *reinterpret_cast<bf8 *>(p + split) = l;
 }
 
+// Two storage forms share every kernel below (template parameter T):
+//   T = bf     planes [hi | lo]: value = hi + lo, `split` channels apart, channel stride 2 * plane      (precision "bf16x3")
+//   T = float  one fp32 plane, `split` unused, channel stride = plane                                    (precision "fp32", round 6)
+template <typename T> struct Lay;
+template <> struct Lay<bf> {
+    static __device__ __forceinline__ void ld(const bf *p, int split, float (&v)[8]) { ld8x(p, split, v); }
+    static __device__ __forceinline__ void ldhi(const bf *p, float (&v)[8]) { ld8(p, v); }          // sign / magnitude class only
+    static __device__ __forceinline__ void st(bf *p, int split, const float (&v)[8]) { st8x(p, split, v); }
+    static __device__ __forceinline__ float ld1(const bf *p, int split) { return (float)p[0] + (float)p[split]; }
+    static __device__ __forceinline__ void st1(bf *p, int split, float v) { const bf h = (bf)v; p[0] = h; p[split] = (bf)(v - (float)h); }
+};
+template <> struct Lay<float> {
+    static __device__ __forceinline__ void ld(const float *p, int, float (&v)[8]) {
+        *reinterpret_cast<f4 *>(v) = *reinterpret_cast<const f4 *>(p);
+        *reinterpret_cast<f4 *>(v + 4) = *reinterpret_cast<const f4 *>(p + 4);
+    }
+    static __device__ __forceinline__ void ldhi(const float *p, float (&v)[8]) { ld(p, 0, v); }
+    static __device__ __forceinline__ void st(float *p, int, const float (&v)[8]) {
+        *reinterpret_cast<f4 *>(p) = *reinterpret_cast<const f4 *>(v);
+        *reinterpret_cast<f4 *>(p + 4) = *reinterpret_cast<const f4 *>(v + 4);
+    }
+    static __device__ __forceinline__ float ld1(const float *p, int) { return p[0]; }
+    static __device__ __forceinline__ void st1(float *p, int, float v) { p[0] = v; }
+};
+
 // ---- per-channel reductions over the pixels of a planes tensor --------------------------------------------------------------
 // MODE 0: s0 = sum x, s1 = sum x^2                       (BatchNorm batch statistics)
 // MODE 1: s0 = sum g, s1 = sum g * xhat                  (BatchNorm backward: g = dy * act'(y), xhat = (x - mean) * invstd)
@@ -51,9 +76,9 @@ __device__ __forceinline__ void st8x(bf *p, int split, const float (&v)[8]) {
 template <typename A> struct Multi { A a[3]; };
 
 struct RedArgs {
-    const bf *x; int x_cs, x_split;          // MODE 0 / 2: the tensor; MODE 1: the convolution output (pre-BN)
-    const bf *dy; int dy_cs, dy_split;       // MODE 1: gradient w.r.t. the activation output
-    const bf *y; int y_cs;                   // MODE 1: activation output, hi plane (sign only); nullptr = recompute the sign from x (scale / shift)
+    const void *x; int x_cs, x_split;        // MODE 0 / 2: the tensor; MODE 1: the convolution output (pre-BN)
+    const void *dy; int dy_cs, dy_split;     // MODE 1: gradient w.r.t. the activation output
+    const void *y; int y_cs;                   // MODE 1: activation output, hi plane (sign only); nullptr = recompute the sign from x (scale / shift)
     const float *mean, *invstd;              // MODE 1
     const float *scale, *shift;              // MODE 1, y == nullptr: the forward's affine (y = x * scale + shift, no residual)
     int act;                                 // MODE 1: 0 none, 1 ReLU, 2 LeakyReLU(0.1)
@@ -61,7 +86,7 @@ struct RedArgs {
     double *partial;
 };
 
-template <int MODE>
+template <int MODE, typename T>
 __global__ __launch_bounds__(256) void reduce_kernel(Multi<RedArgs> mm) {
     __shared__ float sh[2][256][9];
     const RedArgs &a = mm.a[blockIdx.y];
@@ -84,7 +109,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(Multi<RedArgs> mm) {
     if (pl < PL)
         for (long p = p0 + pl; p < p1; p += PL) {
             float x[8];
-            ld8x(a.x + p * a.x_cs + cg * 8, a.x_split, x);
+            Lay<T>::ld((const T *)a.x + p * a.x_cs + cg * 8, a.x_split, x);
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { s0[i] += x[i]; s1[i] += x[i] * x[i]; }
@@ -93,10 +118,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(Multi<RedArgs> mm) {
                 for (int i = 0; i < 8; ++i) s0[i] += x[i];
             } else {
                 float g[8];
-                ld8x(a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
+                Lay<T>::ld((const T *)a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
                 if (a.act) {
                     float y[8];
-                    if (a.y) ld8(a.y + p * a.y_cs + cg * 8, y);
+                    if (a.y) Lay<T>::ldhi((const T *)a.y + p * a.y_cs + cg * 8, y);
                     else {                                   // no residual: the forward's own expression on the same operands gives the same sign
 #pragma unroll
                         for (int i = 0; i < 8; ++i) y[i] = x[i] * sc[i] + sf[i];
@@ -191,12 +216,13 @@ __global__ __launch_bounds__(256) void sum_finish_kernel(const double *__restric
 
 // ---- BatchNorm apply: y = act(x * scale + shift [+ res]) ------------------------------------------------------------------
 struct BnApplyArgs {
-    const bf *x; int x_cs, x_split;
-    const bf *res; int res_cs, res_split;    // residual or nullptr
-    bf *y; int y_cs, y_split;
+    const void *x; int x_cs, x_split;
+    const void *res; int res_cs, res_split;  // residual or nullptr
+    void *y; int y_cs, y_split;
     const float *scale, *shift;
     int act, C; long npix;
 };
+template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(Multi<BnApplyArgs> mm) {
     const BnApplyArgs &a = mm.a[blockIdx.y];
     const int G = a.C >> 3;
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(Multi<BnApplyArgs> mm) {
         const long p = i / G;
         const int cg = (int)(i - p * G);
         float x[8], sc[8], sf[8];
-        ld8x(a.x + p * a.x_cs + cg * 8, a.x_split, x);
+        Lay<T>::ld((const T *)a.x + p * a.x_cs + cg * 8, a.x_split, x);
         *reinterpret_cast<f4 *>(sc) = *reinterpret_cast<const f4 *>(a.scale + cg * 8);
         *reinterpret_cast<f4 *>(sc + 4) = *reinterpret_cast<const f4 *>(a.scale + cg * 8 + 4);
         *reinterpret_cast<f4 *>(sf) = *reinterpret_cast<const f4 *>(a.shift + cg * 8);
@@ -215,7 +241,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(Multi<BnApplyArgs> mm) {
         for (int k = 0; k < 8; ++k) y[k] = x[k] * sc[k] + sf[k];
         if (a.res) {
             float r[8];
-            ld8x(a.res + p * a.res_cs + cg * 8, a.res_split, r);
+            Lay<T>::ld((const T *)a.res + p * a.res_cs + cg * 8, a.res_split, r);
 #pragma unroll
             for (int k = 0; k < 8; ++k) y[k] += r[k];
         }
@@ -226,20 +252,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(Multi<BnApplyArgs> mm) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) y[k] = y[k] > 0.f ? y[k] : y[k] * 0.1f;
         }
-        st8x(a.y + p * a.y_cs + cg * 8, a.y_split, y);
+        Lay<T>::st((T *)a.y + p * a.y_cs + cg * 8, a.y_split, y);
     }
 }
 
 // ---- BatchNorm backward apply: g = dy act'(y); dx = k1 (g - k2 - xhat k3); dres = g ------------------------------------------
 struct BnBwdApplyArgs {
-    const bf *x; int x_cs, x_split;
-    const bf *dy; int dy_cs, dy_split;
-    const bf *y; int y_cs;                   // nullptr = recompute the sign from x (scale / shift), as in reduce_kernel<1>
+    const void *x; int x_cs, x_split;
+    const void *dy; int dy_cs, dy_split;
+    const void *y; int y_cs;                 // nullptr = recompute the sign from x (scale / shift), as in reduce_kernel<1>
     const float *mean, *invstd, *k1, *k2, *k3, *scale, *shift;
-    bf *dx; int dx_cs, dx_split;
-    bf *dres; int dres_cs, dres_split;       // gradient of the residual input (= g) or nullptr
+    void *dx; int dx_cs, dx_split;
+    void *dres; int dres_cs, dres_split;       // gradient of the residual input (= g) or nullptr
     int act, C; long npix;
 };
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(Multi<BnBwdApplyArgs> mm) {
     const BnBwdApplyArgs &a = mm.a[blockIdx.y];
     const int G = a.C >> 3;
@@ -248,11 +275,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(Multi<BnBwdApplyArgs>
         const long p = i / G;
         const int cg = (int)(i - p * G);
         float x[8], g[8];
-        ld8x(a.x + p * a.x_cs + cg * 8, a.x_split, x);
-        ld8x(a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
+        Lay<T>::ld((const T *)a.x + p * a.x_cs + cg * 8, a.x_split, x);
+        Lay<T>::ld((const T *)a.dy + p * a.dy_cs + cg * 8, a.dy_split, g);
         if (a.act) {
             float y[8];
-            if (a.y) ld8(a.y + p * a.y_cs + cg * 8, y);
+            if (a.y) Lay<T>::ldhi((const T *)a.y + p * a.y_cs + cg * 8, y);
             else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) y[k] = x[k] * a.scale[cg * 8 + k] + a.shift[cg * 8 + k];
@@ -268,13 +295,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(Multi<BnBwdApplyArgs>
             const float xh = (x[k] - a.mean[c]) * a.invstd[c];
             d[k] = a.k1[c] * (g[k] - a.k2[c] - xh * a.k3[c]);
         }
-        st8x(a.dx + p * a.dx_cs + cg * 8, a.dx_split, d);
-        if (a.dres) st8x(a.dres + p * a.dres_cs + cg * 8, a.dres_split, g);
+        Lay<T>::st((T *)a.dx + p * a.dx_cs + cg * 8, a.dx_split, d);
+        if (a.dres) Lay<T>::st((T *)a.dres + p * a.dres_cs + cg * 8, a.dres_split, g);
     }
 }
 
 // ---- AvgPool2d(3, 2, 1) backward (count_include_pad): dx[iy, ix] = sum of dy over the windows that hold it / 9 -----------------
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf *__restrict__ dy, int dy_cs, int dy_split, bf *__restrict__ dx, int dx_cs, int dx_split,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T *__restrict__ dy, int dy_cs, int dy_split, T *__restrict__ dx, int dx_cs, int dx_split,
                                                           int B, int H, int W, int Ho, int Wo, int C) {
     const int G = C >> 3;
     const long total = (long)B * H * W * G;
@@ -291,22 +319,23 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf *__restrict__
             for (int ox = ix >> 1; ox <= ((ix + 1) >> 1); ++ox)
                 if (oy < Ho && ox < Wo) {
                     float v[8];
-                    ld8x(dy + ((long)(b * Ho + oy) * Wo + ox) * dy_cs + cg * 8, dy_split, v);
+                    Lay<T>::ld(dy + ((long)(b * Ho + oy) * Wo + ox) * dy_cs + cg * 8, dy_split, v);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) s[k] += v[k];
                 }
 #pragma unroll
         for (int k = 0; k < 8; ++k) s[k] = s[k] / 9.f;
-        st8x(dx + ((long)(b * H + iy) * W + ix) * dx_cs + cg * 8, dx_split, s);
+        Lay<T>::st(dx + ((long)(b * H + iy) * W + ix) * dx_cs + cg * 8, dx_split, s);
     }
 }
 
 // ---- sum of up to four planes tensors (gradients meeting at a fan-out) ----------------------------------------------------------
 struct AddArgs {
-    const bf *in[4]; int cs[4], split[4]; int n;
-    bf *out; int out_cs, out_split;
+    const void *in[4]; int cs[4], split[4]; int n;
+    void *out; int out_cs, out_split;
     int C; long npix;
 };
+template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(AddArgs a) {
     const int G = a.C >> 3;
     const long total = a.npix * G;
@@ -314,14 +343,14 @@ __global__ __launch_bounds__(256) void add_kernel(AddArgs a) {
         const long p = i / G;
         const int cg = (int)(i - p * G);
         float s[8];
-        ld8x(a.in[0] + p * a.cs[0] + cg * 8, a.split[0], s);
+        Lay<T>::ld((const T *)a.in[0] + p * a.cs[0] + cg * 8, a.split[0], s);
         for (int k = 1; k < a.n; ++k) {
             float v[8];
-            ld8x(a.in[k] + p * a.cs[k] + cg * 8, a.split[k], v);
+            Lay<T>::ld((const T *)a.in[k] + p * a.cs[k] + cg * 8, a.split[k], v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] += v[j];
         }
-        st8x(a.out + p * a.out_cs + cg * 8, a.out_split, s);
+        Lay<T>::st((T *)a.out + p * a.out_cs + cg * 8, a.out_split, s);
     }
 }
 
@@ -332,11 +361,12 @@ __global__ __launch_bounds__(256) void add_kernel(AddArgs a) {
 // dextra: channel slice of a planes tensor (the gradient that reaches a stage-1 head through the stage-2 input) or nullptr.
 struct HeadArgs {
     const float *out, *target, *fg;
-    const bf *dextra; int de_cs, de_split;
-    bf *dv; int dv_cs, dv_split;
+    const void *dextra; int de_cs, de_split;
+    void *dv; int dv_cs, dv_split;
     int kind, C, HW; long total; float inv_numel;
     double *partial;
 };
+template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(Multi<HeadArgs> mm) {        // blockIdx.y = head (paf, heat, z)
     __shared__ double sh[4];
     const HeadArgs &a = mm.a[blockIdx.y];
@@ -353,12 +383,10 @@ __global__ __launch_bounds__(256) void head_kernel(Multi<HeadArgs> mm) {        
         e = (double)(d * d * w);
         float g = 2.f * d * w * a.inv_numel;
         const long pix = n * a.HW + p;
-        if (a.dextra) g += (float)a.dextra[pix * a.de_cs + c] + (float)a.dextra[pix * a.de_cs + c + a.de_split];
+        if (a.dextra) g += Lay<T>::ld1((const T *)a.dextra + pix * a.de_cs + c, a.de_split);
         if (a.kind) g *= 4.f;
         const float dv = g * (1.f - s) * s;
-        const bf hi = (bf)dv;
-        a.dv[pix * a.dv_cs + c] = hi;
-        a.dv[pix * a.dv_cs + c + a.dv_split] = (bf)(dv - (float)hi);
+        Lay<T>::st1((T *)a.dv + pix * a.dv_cs + c, a.dv_split, dv);
     }
     // block sum (double): wave shuffles, then four partials through LDS
     for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
@@ -383,7 +411,8 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(Multi<LossFinArgs> mm)
 
 // ---- layout hand-over at the stem (the 7x7 Cin = 1 convolution keeps train.hip's NCHW f32 kernels) and for the legacy weight gradient ----
 // NCHW f32 [B][C][HW] -> planes [B][HW][2 * plane]: 64-pixel x 64-channel tiles through LDS (coalesced on both sides)
-__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__restrict__ in, bf *__restrict__ out, int C, int HW, int out_cs, int out_split) {
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__restrict__ in, T *__restrict__ out, int C, int HW, int out_cs, int out_split) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
     for (int k = threadIdx.x; k < 64 * 64; k += 256) {
@@ -397,11 +426,12 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = tile[cg * 8 + j][p];
-        st8x(out + ((size_t)b * HW + p0 + p) * out_cs + c0 + cg * 8, out_split, v);
+        Lay<T>::st(out + ((size_t)b * HW + p0 + p) * out_cs + c0 + cg * 8, out_split, v);
     }
 }
 // planes -> NCHW f32 [B][Cout][HW]; channel c of the output is channel map[c] of the planes tensor (map == nullptr: c)
-__global__ __launch_bounds__(256) void planes_to_nchw_kernel(const bf *__restrict__ in, int in_cs, int in_split, float *__restrict__ out, int Cout, int HW,
+template <typename T>
+__global__ __launch_bounds__(256) void planes_to_nchw_kernel(const T *__restrict__ in, int in_cs, int in_split, float *__restrict__ out, int Cout, int HW,
                                                              const int *__restrict__ map) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
@@ -411,7 +441,7 @@ __global__ __launch_bounds__(256) void planes_to_nchw_kernel(const bf *__restric
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            if (p0 + p < HW && c0 + cg * 8 < Cout) ld8x(in + ((size_t)b * HW + p0 + p) * in_cs + c0 + cg * 8, in_split, v);
+            if (p0 + p < HW && c0 + cg * 8 < Cout) Lay<T>::ld(in + ((size_t)b * HW + p0 + p) * in_cs + c0 + cg * 8, in_split, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) tile[cg * 8 + j][p] = v[j];
         }
@@ -420,8 +450,7 @@ __global__ __launch_bounds__(256) void planes_to_nchw_kernel(const bf *__restric
             const int p = k >> 6, c = k & 63;
             float v = 0.f;
             if (p0 + p < HW && c0 + c < Cout) {
-                const bf *q = in + ((size_t)b * HW + p0 + p) * in_cs + map[c0 + c];
-                v = (float)q[0] + (float)q[in_split];
+                v = Lay<T>::ld1(in + ((size_t)b * HW + p0 + p) * in_cs + map[c0 + c], in_split);
             }
             tile[c][p] = v;
         }
@@ -439,7 +468,8 @@ __global__ __launch_bounds__(256) void planes_to_nchw_kernel(const bf *__restric
 //   ([cout tile][k-step][lane][8]) and conv4_kernel ([cout block][k-step + 3 spare][8 tiles][lane][8]).
 // transpose = 1 is the data-gradient pack: rows = input channels, k = output channels, taps rotated by 180 degrees.
 struct PackDesc {
-    const float *w; bf *dst;
+    const float *w; void *dst;
+    int f32;                 // 1: fp32 pack of the generic fp32 kernel ([cout tile][k-step][2 halves][lane][4 floats]), one plane pass, no split
     int Cout, Cin, ks;
     int transpose, conv4, CT;
     int rows_valid;          // rows that exist (cout, or the input plane for a transposed pack)
@@ -478,6 +508,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc *__restrict__ 
     const int tap = kstep % KK, hs = kstep / KK;
     const int k0 = hs * 32 + 8 * (lane >> 4);
     bf8 o;
+    float of[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int kidx = k0 + j, pl = kidx / d.kplane, i = kidx - pl * d.kplane;
@@ -495,8 +526,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc *__restrict__ 
         if (co >= 0 && ci >= 0) v = d.w[((size_t)co * d.Cin + ci) * KK + tw];
         const bf h = (bf)v;
         o[j] = pl == 2 ? (bf)(v - (float)h) : h;
+        of[j] = v;
     }
-    *reinterpret_cast<bf8 *>(d.dst + (size_t)g * 8) = o;
+    if (d.f32) {
+        float *fp = (float *)d.dst + (size_t)(g >> 6) * 512 + lane * 4;
+        *reinterpret_cast<f4 *>(fp) = *reinterpret_cast<f4 *>(of);
+        *reinterpret_cast<f4 *>(fp + 256) = *reinterpret_cast<f4 *>(of + 4);
+    } else *reinterpret_cast<bf8 *>((bf *)d.dst + (size_t)g * 8) = o;
 }
 
 // padded copies of the convolution biases (the epilogues read whole cout tiles)

@@ -375,6 +375,163 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgsArgs a) {
                 }
 }
 
+// ---- fp32 form (precision "fp32": exact fp32 FMA chains on v_mfma_f32_16x16x4_f32) -------------------------------------------------------------------
+// K = 4 pixels per MFMA and ONE value per lane and operand: lane (m, kg) multiplies dy[pixel 4 s + kg][co m] with x[pixel 4 s + kg + tap][ci n] -- a channel-minor
+// tensor needs no transpose at all here (16 lanes read 16 consecutive channels).  Same row-streaming rings (five rows of x, five of dy, 256 B per pixel: 80 KB),
+// 16-byte slots XOR-swizzled by the pixel's parity so that the two pixels a half-wave's ds_read_b32 touches fall on different banks.
+struct WgfArgs {
+    const float *x; int x_cs; unsigned x_zero;
+    const float *dy; int dy_cs; unsigned dy_zero;
+    int B, H, W;
+    int Wt, tiles_x, rows_total, rows_per_block;
+    int ncit, co_pad, ci_pad;
+    float *partial;
+};
+
+template <int KS, int D>
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgfArgs a) {
+    typedef __attribute__((address_space(3))) float ldsf;
+    constexpr int KK = KS * KS, PAD = KS / 2, RING = 5;
+    static_assert(KS + D <= RING && 1 + D <= RING, "ring too small for the prefetch distance");
+    constexpr int ROWB = 32 * 256;                          // one row: 32 pixel slots x 64 channels x 4 B
+    constexpr int XRING = RING * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cot = blockIdx.y / a.ncit, cit = blockIdx.y - cot * a.ncit;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int m = lane & 15, kg = lane >> 4;
+    // fragment addresses: pixel 4 s + kg (+ kx), channel window of 16; the channel is XORed with 16 on odd pixels
+    int addrA[2], addrB[KS][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) addrA[mt] = XRING + kg * 256 + ((((wm * 2 + mt) * 16 + m) ^ ((kg & 1) << 4)) << 2);
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) addrB[kx][nt] = (kg + kx) * 256 + ((((wn * 2 + nt) * 16 + m) ^ (((kg + kx) & 1) << 4)) << 2);
+    f4 acc[2][2][KK];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int tp = 0; tp < KK; ++tp) acc[mt][nt][tp] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int o = threadIdx.x * 16; o < 2 * XRING; o += 256 * 16) *reinterpret_cast<u32x4_t *>(smem + o) = u32x4_t{0u, 0u, 0u, 0u};
+
+    // DMA: one instruction = 4 pixels x 16 slots of 16 B; wave w fetches pixel groups w and w + 4 of every row
+    const int dq = lane >> 4, dsp = lane & 15;
+    unsigned lane_x[2], lane_y[2];
+    int dpx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        dpx[h] = (wave + 4 * h) * 4 + dq;
+        const int ls = dsp ^ ((dpx[h] & 1) << 2);
+        lane_x[h] = (unsigned)(((dpx[h] - PAD) * a.x_cs + ci0 + ls * 4) * 4);
+        lane_y[h] = (unsigned)((dpx[h] * a.dy_cs + co0 + ls * 4) * 4);
+    }
+    const unsigned rowx = (unsigned)(a.W * a.x_cs * 4), rowy = (unsigned)(a.W * a.dy_cs * 4);
+    const unsigned dma_lds0 = (unsigned)__builtin_amdgcn_readfirstlane(wave * 1024);
+
+    int row = blockIdx.x * a.rows_per_block;
+    const int row_end = min(row + a.rows_per_block, a.rows_total);
+    while (row < row_end) {
+        const int cs = row / a.H, ya = row - cs * a.H;
+        const int yb = min(a.H, ya + (row_end - row));
+        const int nrows = yb - ya;
+        const int b = cs / a.tiles_x, tx_ = cs - b * a.tiles_x;
+        const int ox0 = tx_ * a.Wt, Wc = min(a.Wt, a.W - ox0);
+        const unsigned bx0 = (unsigned)(((long)b * a.H * a.W + ox0) * (long)a.x_cs * 4);
+        const unsigned by0 = (unsigned)(((long)b * a.H * a.W + ox0) * (long)a.dy_cs * 4);
+        bool okx[2], oky[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            okx[h] = dpx[h] < Wc + 2 * PAD && (unsigned)(ox0 - PAD + dpx[h]) < (unsigned)a.W;
+            oky[h] = dpx[h] < Wc;
+        }
+        auto fetch_x = [&](int n, int slot) {
+            const int Y = ya - PAD + n;
+            const bool rowok = (unsigned)Y < (unsigned)a.H;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned off = (okx[h] && rowok) ? bx0 + (unsigned)Y * rowx + lane_x[h] : a.x_zero;
+                glds16(a.x, off, (unsigned)(slot * ROWB + h * 4096) + dma_lds0);
+            }
+        };
+        auto fetch_y = [&](int n, int slot) {
+            const int Y = ya + n;
+            const bool rowok = Y < yb;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned off = (oky[h] && rowok) ? by0 + (unsigned)Y * rowy + lane_y[h] : a.dy_zero;
+                glds16(a.dy, off, (unsigned)(XRING + slot * ROWB + h * 4096) + dma_lds0);
+            }
+        };
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < KS - 1; ++n) fetch_x(n, n % RING);
+#pragma unroll
+        for (int j = 0; j < D; ++j) { fetch_x(KS - 1 + j, (KS - 1 + j) % RING); fetch_y(j, j % RING); }
+        for (int k0 = 0; k0 < nrows; k0 += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                const int k = k0 + u;
+                if (k >= nrows) break;
+                if (D == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (D == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __syncthreads();
+                fetch_x(KS - 1 + k + D, (KS - 1 + u + D) % RING);
+                fetch_y(k + D, (u + D) % RING);
+                // items (k-step s, tap): the two x values of item i + 1 are requested before the four MFMAs of item i
+                auto ld_a = [&](int s_, float (&A)[2]) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) A[mt] = *(const ldsf *)(smem + addrA[mt] + u * ROWB + s_ * 1024);
+                };
+                auto ld_b = [&](int s_, int tp, float (&Bv)[2]) {
+                    const int ky = tp / KS, kx = tp - ky * KS;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) Bv[nt] = *(const ldsf *)(smem + addrB[kx][nt] + ((u + ky) % RING) * ROWB + s_ * 1024);
+                };
+                float A[2][2], Bq[2][2];
+                ld_a(0, A[0]);
+                ld_b(0, 0, Bq[0]);
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+                    for (int tp = 0; tp < KK; ++tp) {
+                        const int it = s_ * KK + tp, cur = it & 1, nxt = cur ^ 1, ac = s_ & 1;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (tp + 1 < KK) ld_b(s_, tp + 1, Bq[nxt]);
+                        else if (s_ + 1 < 8) { ld_b(s_ + 1, 0, Bq[nxt]); ld_a(s_ + 1, A[ac ^ 1]); }
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ac][mt], Bq[cur][nt], acc[mt][nt][tp], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        row += nrows;
+    }
+    const int g = lane >> 4;
+    float *part = a.partial + (size_t)blockIdx.x * KK * a.co_pad * a.ci_pad;
+#pragma unroll
+    for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + wm * 32 + mt * 16 + 4 * g + i, ci = ci0 + wn * 32 + nt * 16 + (lane & 15);
+                    part[((size_t)tp * a.co_pad + co) * a.ci_pad + ci] = acc[mt][nt][tp][i];
+                }
+}
+
 // dw[co][ref ci][tap] = sum over the split slices, in a fixed order; k_map: this engine's input channel -> the reference's (nullptr = identity).
 // Block = 16 consecutive elements x 16 split lanes: lane l adds slices l, l + 16, ... (independent loads in flight), thread (element, lane 0) adds the
 // 16 lane sums in order.
@@ -411,6 +568,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 
 // Plans the weight gradient of one layer and appends its two launches to `ops`.  *partial_floats grows to what the layer needs; the
 // buffer itself (*partial) is allocated by the caller after every layer has been planned (the kernels read the pointer at launch time).
+inline int plan_wgrad_f32(pn_ctx *ctx, int B, int H, int W, const float *x, int x_plane, const float *dy, int dy_plane, int Cin, int Cout, int ks, const int *k_map, float *dw,
+                          float *const *partial, size_t *partial_floats, std::vector<std::function<int(hipStream_t)>> &ops) {
+    if (ks != 1 && ks != 3) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "fp32 weight gradient: kernel size %d not built", ks);
+    const int KK = ks * ks, pad = ks / 2, seg_max = 32 - 2 * pad;
+    WgfArgs w;
+    memset(&w, 0, sizeof w);
+    w.x = x; w.x_cs = x_plane; w.x_zero = (unsigned)((size_t)B * H * W * x_plane * 4);
+    w.dy = dy; w.dy_cs = dy_plane; w.dy_zero = (unsigned)((size_t)B * H * W * dy_plane * 4);
+    w.B = B; w.H = H; w.W = W;
+    w.tiles_x = (W + seg_max - 1) / seg_max;
+    w.Wt = (W + w.tiles_x - 1) / w.tiles_x;
+    const int ci_my = k_map ? x_plane : Cin;
+    const int ncot = (Cout + 63) / 64;
+    w.ncit = (ci_my + 63) / 64;
+    w.co_pad = ncot * 64; w.ci_pad = w.ncit * 64;
+    if (w.co_pad > dy_plane || w.ci_pad > x_plane) return pn_set_error(ctx, PN_ERR_INVALID, "fp32 weight gradient: channel tiles exceed the tensors");
+    const int pairs = ncot * w.ncit;
+    w.rows_total = B * w.tiles_x * H;
+    int Sr = std::max(1, std::min(w.rows_total, (ctx->num_cus + pairs - 1) / pairs));          // one block per CU (see plan_wgrad)
+    w.rows_per_block = (w.rows_total + Sr - 1) / Sr;
+    Sr = (w.rows_total + w.rows_per_block - 1) / w.rows_per_block;
+    *partial_floats = std::max(*partial_floats, (size_t)Sr * KK * w.co_pad * w.ci_pad);
+    const size_t ldss = (size_t)10 * 8192;
+    ops.push_back([=](hipStream_t s) {
+        WgfArgs ww = w;
+        ww.partial = *partial;
+        if (ks == 3) {
+            static PnLdsAttr attr;
+            if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(wgrad_f32_kernel<3, 2>), ldss)) return rc;
+            hipLaunchKernelGGL((wgrad_f32_kernel<3, 2>), dim3(Sr, pairs), dim3(256), ldss, s, ww);
+        } else {
+            static PnLdsAttr attr;
+            if (int rc = pn_lds_attr(ctx, attr, reinterpret_cast<const void *>(wgrad_f32_kernel<1, 2>), ldss)) return rc;
+            hipLaunchKernelGGL((wgrad_f32_kernel<1, 2>), dim3(Sr, pairs), dim3(256), ldss, s, ww);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((size_t)KK * ww.co_pad * ww.ci_pad + 15) / 16)), dim3(256), 0, s, (const float *)ww.partial, Sr, KK, ww.co_pad, ww.ci_pad, Cout, Cin, k_map, dw);
+        PN_HIP_CHECK(ctx, hipGetLastError());
+        return (int)PN_OK;
+    });
+    return PN_OK;
+}
+
 inline int plan_wgrad(pn_ctx *ctx, int B, int H, int W, const bf *x, int x_plane, const bf *dy, int dy_plane, int Cin, int Cout, int ks, const int *k_map, float *dw,
                       float *const *partial, size_t *partial_floats, std::vector<std::function<int(hipStream_t)>> &ops) {
     if (ks != 1 && ks != 3) return pn_set_error(ctx, PN_ERR_UNSUPPORTED, "weight gradient on planes: kernel size %d not built", ks);
@@ -433,14 +632,14 @@ inline int plan_wgrad(pn_ctx *ctx, int B, int H, int W, const bf *x, int x_plane
     const int pairs = ncot * a.ncit;
     // split-K slices: ONE block per CU.  Every slice costs a 147 KB partial tile written and read back, and a lone 64 KB block leaves the rest of the CU to
     // the BatchNorm / data-gradient launches of the step's own stream (same box, eager step: 1/2 block per CU 7.10 ms, 1: 6.49-6.68, 1.5: 6.93, 2: 7.03, 3: 7.39)
-    static const int per_cu_x2 = getenv("POPNET_TRAINX_WG_BLOCKS") ? atoi(getenv("POPNET_TRAINX_WG_BLOCKS")) : 2;      // blocks per CU, in halves (experiments)
+    const int per_cu_x2 = getenv("POPNET_TRAINX_WG_BLOCKS") ? atoi(getenv("POPNET_TRAINX_WG_BLOCKS")) : 2;      // blocks per CU, in halves (experiments)
     int S = std::max(1, std::min(a.nstrips, (per_cu_x2 * ctx->num_cus / 2 + pairs - 1) / pairs));
     a.strips_per_block = (a.nstrips + S - 1) / S;
     S = (a.nstrips + a.strips_per_block - 1) / a.strips_per_block;
     *partial_floats = std::max(*partial_floats, (size_t)S * KK * a.co_pad * a.ci_pad);
     const size_t lds = (size_t)((R + ks - 1) + R) * 8192;
     const WgArgs a0 = a;
-    static const bool stream_form = !(getenv("POPNET_TRAINX_WG_STREAM") && atoi(getenv("POPNET_TRAINX_WG_STREAM")) == 0);
+    const bool stream_form = !(getenv("POPNET_TRAINX_WG_STREAM") && atoi(getenv("POPNET_TRAINX_WG_STREAM")) == 0);
     if (stream_form) {
         constexpr int D = 2;
         WgsArgs w;

@@ -32,22 +32,25 @@ class TrainEngine:
     """state_dict: reference-format (optionally `module.`-prefixed) rtpose_light3d(15, 14, 2, input_dim=1) checkpoint."""
 
     def __init__(self, state_dict, device="cuda:0", lr=1.0, momentum=0.9, weight_decay=0.0, process_group=None, world_size=1, precision="fp32"):
-        """precision: "fp32" (every product an exact fp32 FMA chain on v_mfma_f32_16x16x4_f32) or "bf16x3" (the 3x3 forward and
-        data-gradient convolutions on split-bf16 MFMA, pn_train_set_precision: fp32 tensors, ~1e-5 relative, faster)."""
+        """precision: "fp32" (every product an exact fp32 FMA chain on v_mfma_f32_16x16x4_f32: the parity mode) or "bf16x3" (split-bf16 MFMA: 16
+        significant bits per operand, fp32 accumulate; 2.5x faster) -- both on the round-6 planes engine (csrc/trainx.hip); "fp32-nchw" / "bf16x3-nchw":
+        the NCHW engine of rounds 2-5 (csrc/train.hip)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.PopnetError("popnet_amd.train: a ROCm device is required -- the HIP path has no CPU fallback")
         self.L = _lib.lib()
         self.ctx = _lib.Context(self.device.index or 0)            # private: its own scratch and precision switch
-        if precision not in ("fp32", "bf16x3", "bf16x3-nchw"):
-            raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16x3-nchw', got %r" % (precision,))
+        if precision not in ("fp32", "bf16x3", "fp32-nchw", "bf16x3-nchw"):
+            raise ValueError("precision must be 'fp32', 'bf16x3', 'fp32-nchw' or 'bf16x3-nchw', got %r" % (precision,))
         self.precision = precision
         # "bf16x3" (round 6): the whole step on NHWC [hi | lo] bf16 planes -- csrc/trainx.hip, one C++ object per batch shape, forward and
         # data-gradient convolutions on the inference kernels, pixel-K MFMA weight gradient.  "bf16x3-nchw": the round 2-5 form (fp32 NCHW
         # tensors, only the 3x3 convolutions split) -- kept for the autograd wrappers' kernels and as a cross-check.
-        self.planes = precision == "bf16x3"
+        # "fp32" (round 6 as well): the same engine on ONE fp32 plane per tensor -- every product an exact fp32 FMA chain (the generic fp32 inference kernel
+        # for forward / data gradient, a K = 4 pixel weight gradient).  "fp32-nchw": the NCHW engine in exact fp32 (what the autograd wrappers call).
+        self.planes = precision in ("bf16x3", "fp32")
         self._trainers = {}
-        self.ctx.check(self.L.pn_train_set_precision(self.ctx.handle, _lib.PN_PREC_BF16X3 if precision != "fp32" else 0), "pn_train_set_precision")
+        self.ctx.check(self.L.pn_train_set_precision(self.ctx.handle, _lib.PN_PREC_BF16X3 if precision.startswith("bf16x3") else 0), "pn_train_set_precision")
         # packed conv weights cached in the (private) context and refreshed by ONE launch at the start of every step (forward_backward)
         self.ctx.check(self.L.pn_train_pack_cache(self.ctx.handle, 1), "pn_train_pack_cache")
         self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
@@ -94,6 +97,7 @@ class TrainEngine:
             tr = self.L.pn_trainer_create(self.ctx.handle)
             if not tr:
                 raise _lib.PopnetError("pn_trainer_create failed")
+            self._check(self.L.pn_trainer_set_precision(tr, _lib.PN_PREC_F32 if self.precision == "fp32" else _lib.PN_PREC_BF16X3), "pn_trainer_set_precision")
             for k, (off, n) in self._offsets.items():
                 self._check(self.L.pn_trainer_set_param(tr, k.encode(), off, n), "pn_trainer_set_param")
             for k, v in self.stats.items():

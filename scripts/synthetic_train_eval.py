@@ -76,19 +76,21 @@ def main():
     ap.add_argument("--steps", type=int, default=6000)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--lr", type=float, default=0.2)
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"])
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "fp32-nchw", "bf16x3-nchw"])
     ap.add_argument("--eval-frames", type=int, default=96)
     ap.add_argument("--pool", type=int, default=40, help="distinct training batches (generated once, cycled)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the initial weights")
+    ap.add_argument("--save", default=None, help="write the trained state_dict here")
+    ap.add_argument("--load", default=None, help="skip the training: evaluate this state_dict (a file written by --save)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     t0 = time.time()
-    pool = [[t.contiguous() for t in targets.mpaug_batch(*scenes(dev, args.batch, 1000 + i))] for i in range(args.pool)]
+    pool = [[t.contiguous() for t in targets.mpaug_batch(*scenes(dev, args.batch, 1000 + i))] for i in range(args.pool if not args.load else 1)]
     t_data = time.time() - t0
-    eng = TrainEngine(synth.init_like_state_dict(seed=args.seed), device=dev, lr=args.lr, precision=args.precision)
+    eng = TrainEngine(synth.init_like_state_dict(seed=args.seed) if not args.load else torch.load(args.load), device=dev, lr=args.lr, precision=args.precision)
     hist = []
     t0 = time.time()
-    for k in range(args.steps):
+    for k in range(args.steps if not args.load else 0):
         if k == 1:
             eng.capture(*pool[1], warmup_steps=0)
         if k == args.steps * 2 // 3:                      # one step-down of the learning rate
@@ -100,6 +102,9 @@ def main():
     torch.cuda.synchronize()
     t_train = time.time() - t0
     sd = {k: v.cpu() for k, v in eng.state_dict().items()}
+    if args.save:
+        torch.save(sd, args.save)
+    del eng
 
     # held-out scenes through the inference engines
     engines = {p: PoseEngine(precision=p, state_dict=sd, device=dev, max_batch=args.batch) for p in ("fp32", "bf16x3", "bf16")}
