@@ -264,8 +264,9 @@ def train_step_cpu(batch, threads=32):
 
 def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=False, precision="fp32", batch_in=None):
     """BASELINE configs[4]: one training step of rtpose_light3d (train-mode forward, rtpose_light3d_loss_fgweight, backward,
-    Nesterov SGD; popnet_amd.train.TrainEngine, fp32, every kernel hand-written HIP) on BATCH frames of 224 x 224 per rank from the
-    reference's initial state, targets built on the GPU; with world > 1 the flat 22 MB gradient is all-reduced every step."""
+    Nesterov SGD; popnet_amd.train.TrainEngine, every kernel hand-written HIP) on BATCH frames of 224 x 224 per rank from the
+    reference's initial state, targets built on the GPU; with world > 1 the flat 22 MB gradient is all-reduced every step.
+    precision "fp32" = the parity mode (exact fp32 FMA chains), "bf16x3" = split-bf16; both on the round-6 planes engine (csrc/trainx.hip)."""
     from popnet_amd import synth
     from popnet_amd.train import TrainEngine
     batch, t_targets = batch_in if batch_in is not None else synth_training_batch(dev, BATCH)
@@ -297,6 +298,8 @@ def train_step_leg(dev, steps=8, warmup=2, world=1, group=None, lr=0.05, cpu=Fal
             "loss_first_step": round(first, 5), "loss_last_step": round(float(t.sum()), 5), "targets_on_gpu_ms_per_batch": round(t_targets * 1e3, 3),
             "launch_mode": ("one C call per step, launches issued from C++ on two HIP streams (eager), update eager" if eng.planes else
                             "hipGraph replay of the step" if world == 1 else "hipGraph replay of forward + backward, all-reduce and update eager"),
+            "engine": ("planes (csrc/trainx.hip): one fp32 plane per tensor, generic fp32 inference kernel for forward / data gradient, K = 4 row-streaming weight gradient" if eng.planes and precision == "fp32"
+                       else "planes (csrc/trainx.hip)" if eng.planes else "NCHW (csrc/train.hip)"),
             "what": "TrainEngine.step: train-mode forward (batch-statistics BatchNorm), fg-weighted loss, backward (MFMA dgrad / wgrad), Nesterov SGD; %s"
                     % ("one all-reduce of the flat gradient per step over %d ranks" % world if world > 1 else "single GPU")}
 
