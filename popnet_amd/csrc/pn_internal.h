@@ -195,6 +195,12 @@ int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, i
                    int C, int in_cs, int out_cs, int out_coff, int in_split, int out_split, hipStream_t stream);
 
 // NCHW f32 -> ReLU -> NHWC T (the multi-channel stem's hand-over, conv_misc.hip)
+// train.hip: model0.conv1 of the planes training engine (trainx.hip) -- output / output gradient as a planes tensor [pixel][cs] (f32 != 0: one
+// f32 plane; else two bf16 planes [hi | lo] `split` elements apart)
+int pn_stem_forward_planes(pn_ctx *ctx, const float *x_dev, const float *w_dev, void *y_planes, int cs, int split, int f32, int N, int Cin, int H, int W, int Cout,
+                           int ks, int stride, int pad, hipStream_t s);
+int pn_stem_wgrad_planes(pn_ctx *ctx, const float *x_dev, const void *dy_planes, int cs, int split, int f32, float *dw_dev, int N, int Cin, int H, int W, int Cout,
+                         int ks, int stride, int pad, hipStream_t s);
 int pn_launch_nchw_relu_to_nhwc(pn_ctx *ctx, int prec, const float *in, void *out, int B, int H, int W, int C, int out_cs, int split, hipStream_t stream);
 // NHWC T channel slice -> NCHW f32 (diagnostics / stage-1 outputs).
 int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, int B, int H, int W,

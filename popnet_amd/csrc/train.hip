@@ -22,7 +22,14 @@ struct TConv {
     int N, Cin, H, W, Cout, Ho, Wo, stride, pad, accumulate;
     int Kdim;            // Cin * KS * KS
     int P;               // N * Ho * Wo
+    // round 6 (the planes training engine's stem, trainx.hip): y / dY as a channel-minor planes tensor [pixel][pl_cs] instead of NCHW f32 --
+    // PL = 1: two bf16 planes [hi | lo] `pl_split` elements apart (value = hi + lo), PL = 2: one f32 plane.  Same values, same MFMA order as the
+    // NCHW form followed / preceded by trainx_kernels.h's layout pass: bit-identical, one 103 MB round trip less each way.
+    void *pl = nullptr;
+    int pl_cs = 0, pl_split = 0;
 };
+typedef __attribute__((ext_vector_type(8))) __bf16 t_bf8;
+typedef __attribute__((ext_vector_type(4))) __bf16 t_bf4;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Forward (and, with flipped weights, the stride-1 data gradient): D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],
@@ -59,7 +66,7 @@ __device__ __forceinline__ int t_logical_block() {
 // weight-gradient grids (column blocks, cout blocks, slices): a slice's blocks are one contiguous logical range
 #define T_DECODE_XYZ(bx, by, bz) const int _lg = t_logical_block(), bx = _lg % (int)gridDim.x, by = (_lg / (int)gridDim.x) % (int)gridDim.y, bz = _lg / (int)(gridDim.x * gridDim.y)
 
-template <int KS>
+template <int KS, int PL = 0>
 __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
     __shared__ float As[TC_KC][TC_AP];
     __shared__ float Bs[TC_KC][TC_BP];
@@ -151,6 +158,31 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TConv c) {
         const int p = p0 + 32 * wave + 16 * n + r;
         const int pok = (int)(p < c.P);
         const int pc = p & -pok;
+        if (PL) {       // planes: this lane's four consecutive couts of a 16-cout tile are one 8-byte (bf16 hi, lo) / 16-byte (f32) store
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int co = co0 + 16 * m + 4 * q;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[m][n][i] + bv[4 * m + i];
+                if (!pok || co >= c.Cout) continue;
+                if (PL == 2) {
+                    *reinterpret_cast<t_f32x4 *>((float *)c.pl + (size_t)pc * c.pl_cs + co) = t_f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    t_bf4 h, l;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const __bf16 hi = (__bf16)v[i];
+                        h[i] = hi;
+                        l[i] = (__bf16)(v[i] - (float)hi);
+                    }
+                    __bf16 *o = (__bf16 *)c.pl + (size_t)pc * c.pl_cs + co;
+                    *reinterpret_cast<t_bf4 *>(o) = h;
+                    *reinterpret_cast<t_bf4 *>(o + c.pl_split) = l;
+                }
+            }
+            continue;
+        }
         const int img = pc / HoWo, rem = pc - img * HoWo;
         float *yb = c.y + (size_t)img * c.Cout * HoWo + rem;
         float old[16];
@@ -1511,7 +1543,7 @@ __global__ void wflip_kernel(const float *__restrict__ w, float *__restrict__ wt
 #define TW_RC 32
 #define TW_P 81
 
-template <int KS>
+template <int KS, int PL = 0>
 __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__restrict__ partial, int pix_per_slice) {
     __shared__ float As[TW_RC][TW_P];      // dY  [pixel][cout]
     __shared__ float Bs[TW_RC][TW_P];      // X   [pixel][k column]
@@ -1536,8 +1568,25 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
     const int pbeg = slice * pix_per_slice, pend = min(pbeg + pix_per_slice, c.P);
     float ra[8], rb[8];
     unsigned okm = 0;          // bit j: rb[j] valid, bit 8 + j: ra[j] valid (the select happens when the values go to LDS)
+    // planes dY: thread = (pixel t >> 3, couts 8 (t & 7) ..+7): one 16-byte load per plane instead of eight strided 4-byte gathers
+    const int a_px = t >> 3, a_co = co0 + 8 * (t & 7);
+    t_bf8 pa_h, pa_l;
+    t_f32x4 pa_f0, pa_f1;
+    bool pa_ok = false;
     auto load = [&](int pc) {
         okm = 0;
+        if (PL) {
+            const int pp = pc + a_px;
+            pa_ok = pp < pend && a_co < c.Cout;
+            const size_t off = (size_t)(pa_ok ? pp : 0) * c.pl_cs + (pa_ok ? a_co : 0);
+            if (PL == 2) {
+                pa_f0 = *reinterpret_cast<const t_f32x4 *>((const float *)c.pl + off);
+                pa_f1 = *reinterpret_cast<const t_f32x4 *>((const float *)c.pl + off + 4);
+            } else {
+                pa_h = *reinterpret_cast<const t_bf8 *>((const __bf16 *)c.pl + off);
+                pa_l = *reinterpret_cast<const t_bf8 *>((const __bf16 *)c.pl + off + c.pl_split);
+            }
+        }
         const int p = pc + pl;
         const bool ok = p < pend;
         int img = 0, rem = 0, oy = 0, ox = 0;
@@ -1553,8 +1602,8 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {            // unconditional loads + selects (see tconv_fwd_kernel)
             const int co = co0 + g + 8 * j;
-            const int oka = (int)(ok & (co < c.Cout));
-            ra[j] = dyb[(co * HoWo) & -oka];
+            const int oka = PL ? 0 : (int)(ok & (co < c.Cout));
+            if (!PL) ra[j] = dyb[(co * HoWo) & -oka];
             const int iy = iy0 + kky[j], ix = ix0 + kkx[j];
             const int okb = (int)(ok & (kci[j] >= 0) & (iy >= 0) & (iy < c.H) & (ix >= 0) & (ix < c.W));
             rb[j] = xb[((kci[j] * c.H + iy) * c.W + ix) & -okb];
@@ -1569,7 +1618,9 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            As[pl][g + 8 * j] = (okm >> (8 + j)) & 1u ? ra[j] : 0.f;
+            if (!PL) As[pl][g + 8 * j] = (okm >> (8 + j)) & 1u ? ra[j] : 0.f;
+            else if (PL == 2) As[a_px][8 * (t & 7) + j] = pa_ok ? (j < 4 ? pa_f0[j & 3] : pa_f1[j & 3]) : 0.f;
+            else As[a_px][8 * (t & 7) + j] = pa_ok ? (float)pa_h[j] + (float)pa_l[j] : 0.f;      // (the layout pass's hi + lo)
             Bs[pl][g + 8 * j] = (okm >> j) & 1u ? rb[j] : 0.f;
         }
         __syncthreads();
@@ -2291,6 +2342,67 @@ int pn_conv2d_wgrad(pn_ctx *ctx, const float *x_dev, const float *dy_dev, float 
     return PN_OK;
 }
 
+}   // extern "C"
+// ---- the planes training engine's stem (trainx.hip; internal, not part of the C ABI) --------------------------------------------------
+// model0.conv1 (rtpose_light3d.py:144: 7x7 / 2, Cin = 1) with its output / its output gradient as a planes tensor (TConv::pl): the kernels,
+// grids, slices and summation order of pn_conv2d_forward / pn_conv2d_wgrad's generic path, without the NCHW f32 hand-over tensor.
+static int t_stem_conv(pn_ctx *ctx, TConv *c, const float *x_dev, void *planes, int cs, int split, int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad) {
+    if (!x_dev || !planes || N < 1 || Cin < 1 || ks != 7 || stride < 1 || pad < 0 || Cout < 8 || (Cout & 7) || cs < Cout || (cs & 7) || (split & 7))
+        return pn_set_error(ctx, PN_ERR_INVALID, "planes stem: bad arguments (7x7, Cout and strides multiples of 8)");
+    c->x = x_dev; c->w = nullptr; c->bias = nullptr; c->y = nullptr;
+    c->N = N; c->Cin = Cin; c->H = H; c->W = W; c->Cout = Cout; c->stride = stride; c->pad = pad; c->accumulate = 0;
+    c->Ho = (H + 2 * pad - ks) / stride + 1;
+    c->Wo = (W + 2 * pad - ks) / stride + 1;
+    c->Kdim = Cin * ks * ks;
+    const long P = (long)N * c->Ho * c->Wo;
+    if (c->Ho < 1 || c->Wo < 1 || P > 0x7fffffffL) return pn_set_error(ctx, PN_ERR_INVALID, "planes stem: size out of range");
+    c->P = (int)P;
+    c->pl = planes; c->pl_cs = cs; c->pl_split = split;
+    return PN_OK;
+}
+
+int pn_stem_forward_planes(pn_ctx *ctx, const float *x_dev, const float *w_dev, void *y_planes, int cs, int split, int f32, int N, int Cin, int H, int W, int Cout,
+                           int ks, int stride, int pad, hipStream_t s) {
+    T_CTX_CHECK("pn_stem_forward_planes")
+    TConv c;
+    if (int rc = t_stem_conv(ctx, &c, x_dev, y_planes, cs, split, N, Cin, H, W, Cout, ks, stride, pad)) return rc;
+    if (!w_dev) return pn_set_error(ctx, PN_ERR_INVALID, "pn_stem_forward_planes: no weights");
+    c.w = w_dev;
+    dim3 grid((unsigned)((c.P + 127) / 128), (unsigned)((Cout + 63) / 64)), block(256);
+    if (f32) hipLaunchKernelGGL((tconv_fwd_kernel<7, 2>), grid, block, 0, s, c);
+    else hipLaunchKernelGGL((tconv_fwd_kernel<7, 1>), grid, block, 0, s, c);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+int pn_stem_wgrad_planes(pn_ctx *ctx, const float *x_dev, const void *dy_planes, int cs, int split, int f32, float *dw_dev, int N, int Cin, int H, int W, int Cout,
+                         int ks, int stride, int pad, hipStream_t s) {
+    T_CTX_CHECK("pn_stem_wgrad_planes")
+    TConv c;
+    if (int rc = t_stem_conv(ctx, &c, x_dev, (void *)dy_planes, cs, split, N, Cin, H, W, Cout, ks, stride, pad)) return rc;
+    if (!dw_dev) return pn_set_error(ctx, PN_ERR_INVALID, "pn_stem_wgrad_planes: no output");
+    const long P = c.P;
+    // (the slices of pn_conv2d_wgrad's generic path: the same partial sums in the same order)
+    const int tiles = ((c.Kdim + 63) / 64) * ((Cout + 63) / 64);
+    long slices = (1024 + tiles - 1) / tiles;
+    const long cap = (P + 1023) / 1024;
+    if (slices > cap) slices = cap;
+    if (slices < 1) slices = 1;
+    long pps = (P + slices - 1) / slices;
+    pps = (pps + TW_RC - 1) / TW_RC * TW_RC;
+    slices = (P + pps - 1) / pps;
+    const size_t wn = (size_t)Cout * c.Kdim;
+    void *ws = nullptr;
+    if (int rc = t_ws(ctx, wn * slices * sizeof(float) + 16, &ws)) return rc;
+    dim3 grid((unsigned)((c.Kdim + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)slices), block(256);
+    if (f32) hipLaunchKernelGGL((tconv_wgrad_kernel<7, 2>), grid, block, 0, s, c, (float *)ws, (int)pps);
+    else hipLaunchKernelGGL((tconv_wgrad_kernel<7, 1>), grid, block, 0, s, c, (float *)ws, (int)pps);
+    t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)slices);
+    PN_HIP_CHECK(ctx, hipGetLastError());
+    return PN_OK;
+}
+
+extern "C" {
 int pn_bn_train_forward(pn_ctx *ctx, const float *x_dev, const float *gamma_dev, const float *beta_dev, const float *res_dev, float *y_dev,
                         float *save_mean_dev, float *save_invstd_dev, float *running_mean_dev, float *running_var_dev, float momentum, float eps,
                         int act, int N, int C, int HW, void *hip_stream) {

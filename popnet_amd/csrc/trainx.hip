@@ -648,7 +648,9 @@ int build(pn_trainer *t) {
     t->nchw_elems = std::max(t->nchw_elems, (size_t)B * 64 * H2 * W2);
     {
         const TxTensor c0 = t->T[C0];
+        const bool handover = getenv("POPNET_TRAINX_STEM_HANDOVER") != nullptr;      // the NCHW f32 hand-over of the round's first builds (bit-identical; A/B)
         t->ops.push_back([=](hipStream_t s) {
+            if (!handover) return pn_stem_forward_planes(t->ctx, t->img, w_stem, c0.p, c0.cs(), c0.split(), t->f32, B, 1, H, W, 64, 7, 2, 3, s);
             if (int r = pn_conv2d_forward(t->ctx, t->img, w_stem, nullptr, t->nchw_a, B, 1, H, W, 64, 7, 2, 3, 0, (void *)s)) return r;
             const int HW = H2 * W2;
             if (t->f32) hipLaunchKernelGGL(tx::nchw_to_planes_kernel<float>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)t->nchw_a, (float *)c0.p, 64, HW, c0.cs(), 0);
@@ -824,7 +826,9 @@ int build(pn_trainer *t) {
     op_bn_bwd(t, bn_stem, C0, dA0, A0, dC0, -1, 1, false);
     {
         const TxTensor d0 = t->T[dC0];
+        const bool handover = getenv("POPNET_TRAINX_STEM_HANDOVER") != nullptr;
         t->ops.push_back([=](hipStream_t s) {
+            if (!handover) return pn_stem_wgrad_planes(t->ctx, t->img, d0.p, d0.cs(), d0.split(), t->f32, dw_stem, B, 1, H, W, 64, 7, 2, 3, s);
             const int HW = H2 * W2;
             if (t->f32) hipLaunchKernelGGL(tx::planes_to_nchw_kernel<float>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)d0.p, d0.cs(), 0, t->nchw_b, 64, HW, (const int *)nullptr);
             else hipLaunchKernelGGL(tx::planes_to_nchw_kernel<bf>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const bf *)d0.p, d0.cs(), d0.plane, t->nchw_b, 64, HW, (const int *)nullptr);

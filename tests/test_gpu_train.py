@@ -502,7 +502,8 @@ def test_planes_engine_at_ragged_sizes_vs_oracle_and_nchw_engine(gpu, golden, si
 def test_planes_engine_weight_gradient_kernel_and_stream_split_are_exact_restatements(gpu, golden, monkeypatch, prec):
     """(1) trainx_wgrad.h (pixel-K MFMA GEMM through ds_read_b64_tr_b16) against train.hip's NCHW weight-gradient kernels fed the SAME planes (POPNET_TRAINX_WGRAD=legacy:
     the operands are handed over as fp32 = hi + lo, which re-splits to the same hi / lo): same products, another summation order -- every convolution weight gradient
-    within 2e-5 of the other; (2) the two-stream schedule (weight gradients beside the BatchNorm / data-gradient chain) against the one-stream one: bit-identical."""
+    within 2e-5 of the other; (2) the two-stream schedule (weight gradients beside the BatchNorm / data-gradient chain) against the one-stream one: bit-identical;
+    (3) the stem writing / reading planes directly against the NCHW f32 hand-over tensors of the round's first builds (POPNET_TRAINX_STEM_HANDOVER=1): bit-identical."""
     from popnet_amd.train import TrainEngine
     sd = init_like_state_dict(golden.keys["rtpose_light3d"], seed=7)
     batch = [torch.from_numpy(a).to(gpu) for a in train_case_inputs(seed=910, B=2, H=96, W=64)]
@@ -519,6 +520,11 @@ def test_planes_engine_weight_gradient_kernel_and_stream_split_are_exact_restate
     two, t2 = run()
     one, t1 = run(POPNET_TRAINX_STREAMS="1")
     assert torch.equal(t1, t2) and torch.equal(one.flat_g, two.flat_g)
+    hand, th = run(POPNET_TRAINX_STEM_HANDOVER="1")
+    assert torch.equal(th, t2) and torch.equal(hand.flat_g, two.flat_g)
+    assert float(two.g["model0.conv1.weight"].abs().max()) > 0
+    for k in two.stats:
+        assert torch.equal(hand.stats[k], two.stats[k]), k
     leg, tl = run(POPNET_TRAINX_WGRAD="legacy")
     assert torch.equal(tl, t2)
     worst = 0.0
