@@ -88,7 +88,8 @@ struct pn_trainer {
     std::vector<tx::BiasDesc> biases;
     tx::PackDesc *packs_dev = nullptr;
     tx::BiasDesc *biases_dev = nullptr;
-    unsigned pack_groups = 0;
+    unsigned pack_groups = 0, pack_units = 0;
+    bool pack_gather = false;          // POPNET_TRAINX_PACK=gather: round 6's first pack kernel (one thread per 16-byte group; bit-identical)
     float *zero_bias = nullptr;
     int *cat_k_map = nullptr, *cat_ref_map = nullptr;           // [192] my channel -> reference channel ; [187] reference -> my channel
     double *partial = nullptr; size_t partial_doubles = 0;
@@ -204,6 +205,8 @@ int ensure_pack(pn_trainer *t, const PlannedConv &pc, bf **dst_out) {
     d.k_map = (!pc.u.dgrad && L.cat) ? t->cat_k_map : nullptr;
     d.first_group = t->pack_groups; d.ngroups = (unsigned)real_groups;
     t->pack_groups += (unsigned)real_groups;
+    d.first_unit = t->pack_units; d.nunits = (unsigned)((size_t)pc.cout_pad * pc.kplane / 8);
+    t->pack_units += d.nunits;
     t->packs.push_back(d);
     *dst_out = slot;
     return PN_OK;
@@ -634,7 +637,8 @@ int build(pn_trainer *t) {
     TX(op_fork(t));
     const size_t pack_from = t->ops.size();
     t->ops.push_back([t](hipStream_t s) {
-        if (t->pack_groups) hipLaunchKernelGGL(tx::pack_kernel, dim3((t->pack_groups + 255) / 256), dim3(256), 0, s, (const tx::PackDesc *)t->packs_dev, (int)t->packs.size(), t->pack_groups);
+        if (t->pack_groups && t->pack_gather) hipLaunchKernelGGL(tx::pack_kernel, dim3((t->pack_groups + 255) / 256), dim3(256), 0, s, (const tx::PackDesc *)t->packs_dev, (int)t->packs.size(), t->pack_groups);
+        else if (t->pack_units) hipLaunchKernelGGL(tx::pack_rows_kernel, dim3((t->pack_units + 255) / 256), dim3(256), 0, s, (const tx::PackDesc *)t->packs_dev, (int)t->packs.size(), t->pack_units);
         if (!t->biases.empty()) hipLaunchKernelGGL(tx::bias_kernel, dim3((unsigned)t->biases.size()), dim3(128), 0, s, (const tx::BiasDesc *)t->biases_dev, (int)t->biases.size());
         PN_HIP_CHECK(t->ctx, hipGetLastError());
         return (int)PN_OK;
@@ -908,6 +912,8 @@ int pn_trainer_finalize(pn_trainer *t, float *flat_param_dev, float *flat_grad_d
     t->flat_p = flat_param_dev; t->flat_g = flat_grad_dev; t->B = B; t->H = H; t->W = W; t->momentum = bn_momentum; t->eps = bn_eps;
     const char *e = getenv("POPNET_TRAINX_WGRAD");
     t->legacy_wgrad = e && !strcmp(e, "legacy");
+    const char *epk = getenv("POPNET_TRAINX_PACK");
+    t->pack_gather = epk && !strcmp(epk, "gather");
     const char *e2 = getenv("POPNET_TRAINX_STREAMS");
     t->two_streams = !(e2 && atoi(e2) == 1) && !t->legacy_wgrad;
     if (const char *e3 = getenv("POPNET_TRAINX_SIDES")) t->nside = std::max(1, std::min(4, atoi(e3)));

@@ -477,7 +477,8 @@ struct PackDesc {
     int ksteps;              // 3 * kplane / 64 * ks * ks * 2
     const int *row_map;      // transposed pack: row -> reference input channel (nullptr = identity); -1 = zero row
     const int *k_map;        // forward pack: plane channel -> reference input channel (nullptr = identity); -1 = zero column
-    unsigned first_group, ngroups;      // 16-byte groups of this pack in the launch
+    unsigned first_group, ngroups;      // 16-byte groups of this pack in the launch (pack_kernel)
+    unsigned first_unit, nunits;        // (row, 8 k-channels) units of this pack in the launch (pack_rows_kernel)
 };
 __device__ __forceinline__ int row_channel(int tile, int row, int CT) { return (tile / CT) * CT * 16 + 4 * CT * (row >> 2) + 4 * (tile % CT) + (row & 3); }
 
@@ -533,6 +534,107 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc *__restrict__ 
         *reinterpret_cast<f4 *>(fp) = *reinterpret_cast<f4 *>(of);
         *reinterpret_cast<f4 *>(fp + 256) = *reinterpret_cast<f4 *>(of + 4);
     } else *reinterpret_cast<bf8 *>((bf *)d.dst + (size_t)g * 8) = o;
+}
+
+// The same packs, one thread per (row, 8 k-channels): the 8 x ks x ks parameters are read ONCE (a forward pack's are 288 contiguous bytes) and leave as
+// the 3 x ks x ks groups that hold them -- every tap's k-step of the three plane passes [W_hi | W_hi | W_lo].  pack_kernel above gathers them per group:
+// eight 4-byte loads 36 bytes apart for every one of the 27 groups (37 M gathers per step, 104 us beside the stem; this form: see profiles/r06_notes.txt).
+// A wave = the 64 lanes of one fragment, so every (plane pass, tap) store of a wave is one contiguous KB.
+template <int KK>
+__device__ __forceinline__ void pack_rows_body(const PackDesc &d, unsigned u) {
+    const int lane = (int)(u & 63u), r = lane & 15, igl = lane >> 4;
+    const int hpp = d.kplane >> 5;                  // 32-channel halves per plane
+    const unsigned rest = u >> 6;
+    const int hh = (int)(rest % (unsigned)hpp), tile = (int)(rest / (unsigned)hpp);
+    const int i0 = hh * 32 + igl * 8;
+    int row;
+    size_t gbase, gstride;
+    if (d.conv4) {
+        const int cbk = tile >> 3, t = tile & 7;
+        row = cbk * 128 + row_channel(t, r, 4);
+        gbase = ((size_t)cbk * (d.ksteps + 3) * 8 + t) * 64 + lane;
+        gstride = 512;
+    } else {
+        row = row_channel(tile, r, d.CT);
+        gbase = (size_t)tile * d.ksteps * 64 + lane;
+        gstride = 64;
+    }
+    float v[8][KK];                                 // [k channel][tap of the PACK]
+    if (!d.transpose) {
+        const int co = row < d.rows_valid ? row : -1;
+        if (co >= 0 && !d.k_map && i0 + 8 <= d.Cin) {
+            const float *src = d.w + ((size_t)co * d.Cin + i0) * KK;
+            if ((((size_t)src) & 15) == 0) {                  // (TrainEngine's flat buffers start every tensor on 16 bytes)
+                float flat[8 * KK];
+#pragma unroll
+                for (int k = 0; k < 8 * KK / 4; ++k) *reinterpret_cast<f4 *>(flat + 4 * k) = *reinterpret_cast<const f4 *>(src + 4 * k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int t = 0; t < KK; ++t) v[j][t] = flat[j * KK + t];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int t = 0; t < KK; ++t) v[j][t] = src[j * KK + t];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j;
+                const int ci = d.k_map ? d.k_map[i] : (i < d.Cin ? i : -1);
+                const bool ok = co >= 0 && ci >= 0;
+                const float *src = d.w + (ok ? ((size_t)co * d.Cin + ci) * KK : 0);
+#pragma unroll
+                for (int t = 0; t < KK; ++t) { const float x = src[t]; v[j][t] = ok ? x : 0.f; }
+            }
+        }
+    } else {
+        const int ci = row < d.rows_valid ? (d.row_map ? d.row_map[row] : (row < d.Cin ? row : -1)) : -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int co = i0 + j < d.Cout ? i0 + j : -1;
+            const bool ok = co >= 0 && ci >= 0;
+            const float *src = d.w + (ok ? ((size_t)co * d.Cin + ci) * KK : 0);
+#pragma unroll
+            for (int t = 0; t < KK; ++t) { const float x = src[KK - 1 - t]; v[j][t] = ok ? x : 0.f; }      // taps rotated by 180 degrees
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        const size_t g0 = gbase + (size_t)(hh * KK + t) * gstride;             // plane pass 0; pass pl: + pl * hpp * KK k-steps
+        const size_t gpl = (size_t)hpp * KK * gstride;
+        if (d.f32) {
+            float *fp = (float *)d.dst + (g0 >> 6) * 512 + lane * 4;
+            *reinterpret_cast<f4 *>(fp) = f4{v[0][t], v[1][t], v[2][t], v[3][t]};
+            *reinterpret_cast<f4 *>(fp + 256) = f4{v[4][t], v[5][t], v[6][t], v[7][t]};
+        } else {
+            bf8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf hi = (bf)v[j][t];
+                h[j] = hi;
+                l[j] = (bf)(v[j][t] - (float)hi);
+            }
+            bf *o = (bf *)d.dst;
+            *reinterpret_cast<bf8 *>(o + g0 * 8) = h;
+            *reinterpret_cast<bf8 *>(o + (g0 + gpl) * 8) = h;
+            *reinterpret_cast<bf8 *>(o + (g0 + 2 * gpl) * 8) = l;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(const PackDesc *__restrict__ tab, int n, unsigned total_units) {
+    const unsigned uid = blockIdx.x * 256u + threadIdx.x;
+    if (uid >= total_units) return;
+    int lo = 0, hi = n - 1;                         // the pack that holds this unit
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_unit <= uid) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = tab[lo];
+    if (d.ks == 3) pack_rows_body<9>(d, uid - d.first_unit);
+    else pack_rows_body<1>(d, uid - d.first_unit);
 }
 
 // padded copies of the convolution biases (the epilogues read whole cout tiles)
