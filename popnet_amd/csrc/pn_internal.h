@@ -199,8 +199,15 @@ int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, i
 // f32 plane; else two bf16 planes [hi | lo] `split` elements apart)
 int pn_stem_forward_planes(pn_ctx *ctx, const float *x_dev, const float *w_dev, void *y_planes, int cs, int split, int f32, int N, int Cin, int H, int W, int Cout,
                            int ks, int stride, int pad, hipStream_t s);
-int pn_stem_wgrad_planes(pn_ctx *ctx, const float *x_dev, const void *dy_planes, int cs, int split, int f32, float *dw_dev, int N, int Cin, int H, int W, int Cout,
-                         int ks, int stride, int pad, hipStream_t s);
+// bn != nullptr: `dy_planes` is the gradient w.r.t. the BatchNorm + activation OUTPUT and the kernel applies the BatchNorm backward itself (k1, k2, k3: what
+// trainx_kernels.h::bn_bwd_finish_kernel leaves); depth = chunks of 32 pixels in flight per block (1 or 4)
+struct PnStemBn {
+    const void *x; int x_cs, x_split;
+    const float *mean, *invstd, *k1, *k2, *k3, *scale, *shift;
+    int act;
+};
+int pn_stem_wgrad_planes(pn_ctx *ctx, const float *x_dev, const void *dy_planes, int cs, int split, int f32, const PnStemBn *bn, float *dw_dev, int N, int Cin, int H,
+                         int W, int Cout, int ks, int stride, int pad, int depth, hipStream_t s);
 int pn_launch_nchw_relu_to_nhwc(pn_ctx *ctx, int prec, const float *in, void *out, int B, int H, int W, int C, int out_cs, int split, hipStream_t stream);
 // NHWC T channel slice -> NCHW f32 (diagnostics / stage-1 outputs).
 int pn_launch_nhwc_to_nchw(pn_ctx *ctx, int prec, const void *in, float *out, int B, int H, int W,

@@ -30,6 +30,7 @@ struct TConv {
 };
 typedef __attribute__((ext_vector_type(8))) __bf16 t_bf8;
 typedef __attribute__((ext_vector_type(4))) __bf16 t_bf4;
+typedef __attribute__((ext_vector_type(2))) float t_f32x2;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Forward (and, with flipped weights, the stride-1 data gradient): D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],
@@ -1543,7 +1544,7 @@ __global__ void wflip_kernel(const float *__restrict__ w, float *__restrict__ wt
 #define TW_RC 32
 #define TW_P 81
 
-template <int KS, int PL = 0>
+template <int KS>
 __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__restrict__ partial, int pix_per_slice) {
     __shared__ float As[TW_RC][TW_P];      // dY  [pixel][cout]
     __shared__ float Bs[TW_RC][TW_P];      // X   [pixel][k column]
@@ -1568,25 +1569,8 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
     const int pbeg = slice * pix_per_slice, pend = min(pbeg + pix_per_slice, c.P);
     float ra[8], rb[8];
     unsigned okm = 0;          // bit j: rb[j] valid, bit 8 + j: ra[j] valid (the select happens when the values go to LDS)
-    // planes dY: thread = (pixel t >> 3, couts 8 (t & 7) ..+7): one 16-byte load per plane instead of eight strided 4-byte gathers
-    const int a_px = t >> 3, a_co = co0 + 8 * (t & 7);
-    t_bf8 pa_h, pa_l;
-    t_f32x4 pa_f0, pa_f1;
-    bool pa_ok = false;
     auto load = [&](int pc) {
         okm = 0;
-        if (PL) {
-            const int pp = pc + a_px;
-            pa_ok = pp < pend && a_co < c.Cout;
-            const size_t off = (size_t)(pa_ok ? pp : 0) * c.pl_cs + (pa_ok ? a_co : 0);
-            if (PL == 2) {
-                pa_f0 = *reinterpret_cast<const t_f32x4 *>((const float *)c.pl + off);
-                pa_f1 = *reinterpret_cast<const t_f32x4 *>((const float *)c.pl + off + 4);
-            } else {
-                pa_h = *reinterpret_cast<const t_bf8 *>((const __bf16 *)c.pl + off);
-                pa_l = *reinterpret_cast<const t_bf8 *>((const __bf16 *)c.pl + off + c.pl_split);
-            }
-        }
         const int p = pc + pl;
         const bool ok = p < pend;
         int img = 0, rem = 0, oy = 0, ox = 0;
@@ -1602,8 +1586,8 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {            // unconditional loads + selects (see tconv_fwd_kernel)
             const int co = co0 + g + 8 * j;
-            const int oka = PL ? 0 : (int)(ok & (co < c.Cout));
-            if (!PL) ra[j] = dyb[(co * HoWo) & -oka];
+            const int oka = (int)(ok & (co < c.Cout));
+            ra[j] = dyb[(co * HoWo) & -oka];
             const int iy = iy0 + kky[j], ix = ix0 + kkx[j];
             const int okb = (int)(ok & (kci[j] >= 0) & (iy >= 0) & (iy < c.H) & (ix >= 0) & (ix < c.W));
             rb[j] = xb[((kci[j] * c.H + iy) * c.W + ix) & -okb];
@@ -1618,9 +1602,7 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (!PL) As[pl][g + 8 * j] = (okm >> (8 + j)) & 1u ? ra[j] : 0.f;
-            else if (PL == 2) As[a_px][8 * (t & 7) + j] = pa_ok ? (j < 4 ? pa_f0[j & 3] : pa_f1[j & 3]) : 0.f;
-            else As[a_px][8 * (t & 7) + j] = pa_ok ? (float)pa_h[j] + (float)pa_l[j] : 0.f;      // (the layout pass's hi + lo)
+            As[pl][g + 8 * j] = (okm >> (8 + j)) & 1u ? ra[j] : 0.f;
             Bs[pl][g + 8 * j] = (okm >> j) & 1u ? rb[j] : 0.f;
         }
         __syncthreads();
@@ -1640,6 +1622,181 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = co0 + 16 * wave + 4 * q + i;
+            if (co < c.Cout) pb[(size_t)co * c.Kdim + k] = acc[n][i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The planes training engine's stem weight gradient (round 6): tconv_wgrad_kernel above -- the same block roles for the MFMAs, the same
+// slices, the same order of every sum: bit-identical partials -- with
+//   * dY read from a planes tensor ([pixel][cs], two bf16 planes hi | lo or one f32 plane): thread = (pixel t >> 3, couts 8 (t & 7) ..+7),
+//     one 16-byte load per plane instead of eight strided 4-byte gathers of an NCHW hand-over tensor;
+//   * BN = 1: dY is not read but computed -- the stem's BatchNorm backward (trainx_kernels.h::bn_bwd_apply_kernel: g = dA * ReLU'(x * scale + shift),
+//     d = k1 * (g - k2 - xhat * k3), rounded to hi + lo exactly as that kernel stores it) from the activation gradient and the convolution
+//     output, so the 103 MB dC0 tensor is neither written nor read;
+//   * EIGHT waves per slice instead of four: the kernel is bound by its vector instructions (pixel decomposition, halo tests, the BatchNorm arithmetic, b32
+//     LDS stores: ~1 600 issue cycles per wave and chunk against 1 024 of MFMA; four chunks in flight instead of one changed nothing), and 392 slices on
+//     256 CUs leave 136 CUs with two blocks: with half the staging work per wave a slice takes half as long.  Wave w accumulates cout tile w & 3 x k-column
+//     tiles 2 (w >> 2), 2 (w >> 2) + 1 -- every accumulator sees the MFMAs of tconv_wgrad_kernel in the same order;
+//   * D chunks in flight (template parameter; every load of a slot issued unconditionally and the prologue in slot order, or the compiler closes each
+//     iteration with s_waitcnt vmcnt(0)): measured 105.8 / 111.2 / 116.1 us for D = 1 / 2 / 4 on one box -- the launch is bound by instruction issue
+//     (~270 instructions per wave and 32-pixel chunk for 16 MFMAs), not by memory latency; D = 1 is the default.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TStemBn {
+    const void *x; int x_cs, x_split;            // the convolution output (planes, as dY)
+    const float *mean, *invstd, *k1, *k2, *k3, *scale, *shift;
+    int act;                                     // 0 none, 1 ReLU, 2 LeakyReLU(0.1); the sign comes from x * scale + shift
+};
+template <int KS, int F32, int BN, int D>
+__global__ __launch_bounds__(512, 1) void tstem_wgrad_kernel(TConv c, TStemBn bn, float *__restrict__ partial, int pix_per_slice) {
+    __shared__ float As[TW_RC][TW_P];      // dY  [pixel][cout]
+    __shared__ float Bs[TW_RC][TW_P];      // X   [pixel][k column]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    const int mt = wave & 3, nh = wave >> 2;            // this wave's cout tile and pair of k-column tiles
+    T_DECODE_XYZ(bx_, by_, slice);
+    const int kc0 = bx_ * 64, co0 = by_ * 64;
+    const int HoWo = c.Ho * c.Wo;
+    const int pl = t & 31, g = t >> 5;                  // X staging: pixel, k columns g + 16 j
+    // (the vector instructions bound this kernel: everything that does not change from chunk to chunk is decided here -- a k column's offset inside the
+    // image and its (ky, kx); an invalid column gets ky = -2^20, which fails the halo test)
+    int koff[4], kky[4], kkx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = kc0 + g + 16 * j;
+        if (k < c.Kdim) {
+            const int ci = k / (KS * KS), rr = k - ci * (KS * KS);
+            kky[j] = rr / KS;
+            kkx[j] = rr - kky[j] * KS;
+            koff[j] = (ci * c.H + kky[j]) * c.W + kkx[j];
+        } else {
+            koff[j] = 0; kky[j] = -(1 << 20); kkx[j] = 0;
+        }
+    }
+    const int pbeg = slice * pix_per_slice, pend = min(pbeg + pix_per_slice, c.P);
+    const int a_px = t >> 4, a_c4 = 4 * (t & 15), a_co = co0 + a_c4;       // dY staging: pixel, couts a_c4 ..+3
+    const bool a_cok = a_co < c.Cout;
+    float bmean[4], binv[4], bk1[4], bk2[4], bk3[4], bsc[4], bsh[4];
+    if (BN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = a_cok ? a_co + j : 0;
+            bmean[j] = bn.mean[ch]; binv[j] = bn.invstd[ch]; bk1[j] = bn.k1[ch]; bk2[j] = bn.k2[ch]; bk3[j] = bn.k3[ch]; bsc[j] = bn.scale[ch]; bsh[j] = bn.shift[ch];
+        }
+    }
+    // per prefetch slot: raw dY (and x) vectors, the gathered input values, validity bits (the selects happen when the values go to LDS)
+    t_f32x4 dyv[D], xv[D];                 // f32: four floats; bf16 planes: .xy = the hi plane's 4 x bf16, .zw = the lo plane's
+    float rb[D][4];
+    unsigned okm[D];
+    const int adv_i = TW_RC / HoWo, adv_y = (TW_RC - adv_i * HoWo) / c.Wo, adv_x = TW_RC - adv_i * HoWo - adv_y * c.Wo;
+    int w_img, w_oy, w_ox;
+    {
+        const int p = min(pbeg + pl, c.P - 1);
+        w_img = p / HoWo;
+        const int rem = p - w_img * HoWo;
+        w_oy = rem / c.Wo;
+        w_ox = rem - w_oy * c.Wo;
+    }
+    auto ldplanes = [&](const void *base, size_t off, int split) -> t_f32x4 {
+        if (F32) return *reinterpret_cast<const t_f32x4 *>((const float *)base + off);
+        const t_f32x2 h = *reinterpret_cast<const t_f32x2 *>((const __bf16 *)base + off), l = *reinterpret_cast<const t_f32x2 *>((const __bf16 *)base + off + split);
+        return t_f32x4{h[0], h[1], l[0], l[1]};
+    };
+    auto load = [&](int d, int pc) {
+        const int pp = pc + a_px;
+        const bool aok = pp < pend && a_cok;
+        dyv[d] = ldplanes(c.pl, (size_t)(aok ? pp : 0) * c.pl_cs + (aok ? a_co : 0), c.pl_split);
+        if (BN) xv[d] = ldplanes(bn.x, (size_t)(aok ? pp : 0) * bn.x_cs + (aok ? a_co : 0), bn.x_split);
+        unsigned m = (unsigned)aok << 8;
+        // this thread's pixel of the chunk: (img, oy, ox) walk along with the chunks (loads are issued in chunk order), no division per chunk
+        const bool ok = pc + pl < pend;
+        const int iy0 = w_oy * c.stride - c.pad, ix0 = w_ox * c.stride - c.pad;
+        const float *xb = c.x + (size_t)w_img * c.Cin * c.H * c.W + (iy0 * c.W + ix0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int okb = (int)(ok & ((unsigned)(iy0 + kky[j]) < (unsigned)c.H) & ((unsigned)(ix0 + kkx[j]) < (unsigned)c.W));
+            const float *src = okb ? xb + koff[j] : c.x;        // (an unconditional load + a select later, see tconv_fwd_kernel)
+            rb[d][j] = *src;
+            m |= (unsigned)okb << j;
+        }
+        okm[d] = m;
+        w_ox += adv_x; w_oy += adv_y; w_img += adv_i;             // the next chunk's pixel: 32 further (one carry per digit at most)
+        if (w_ox >= c.Wo) { w_ox -= c.Wo; ++w_oy; }
+        if (w_oy >= c.Ho) { w_oy -= c.Ho; ++w_img; }
+    };
+    auto value4 = [&](const t_f32x4 raw, float (&v)[4]) {           // a planes vector as trainx_kernels.h::Lay<T>::ld reads it
+        if (F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = raw[j];
+        } else {
+            const t_bf4 h = __builtin_bit_cast(t_bf4, t_f32x2{raw[0], raw[1]}), l = __builtin_bit_cast(t_bf4, t_f32x2{raw[2], raw[3]});
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (float)h[j] + (float)l[j];
+        }
+    };
+    t_f32x4 acc[2];
+    acc[0] = acc[1] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    // every load of a slot is issued UNCONDITIONALLY (a chunk behind the slice's end reads dummy addresses and is never used): with the loads inside
+    // `if (pc < pend)` the loop body is not straight-line and the compiler closes every iteration with s_waitcnt vmcnt(0) -- no chunk stays in flight
+    // (and the prologue issues the slots IN ORDER: the scheduler had moved the loads the loop needs first to the end of the prologue, which the counter
+    // of the loop's first wait then had to allow for)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        load(d, pbeg + d * TW_RC);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int pc0 = pbeg; pc0 < pend; pc0 += D * TW_RC) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int pc = pc0 + d * TW_RC;
+            if (pc >= pend) break;
+            float a4[4];
+            value4(dyv[d], a4);
+            if (BN) {
+                float x4[4];
+                value4(xv[d], x4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float gg = a4[j];
+                    if (bn.act) {
+                        const float y = x4[j] * bsc[j] + bsh[j];
+                        const float neg = bn.act == 2 ? 0.1f : 0.f;
+                        gg = y > 0.f ? gg : gg * neg;
+                    }
+                    const float xh = (x4[j] - bmean[j]) * binv[j];
+                    float dd = bk1[j] * (gg - bk2[j] - xh * bk3[j]);
+                    if (!F32) {                                            // what Lay<bf>::st stores and Lay<bf>::ld reads back
+                        const __bf16 hi = (__bf16)dd;
+                        dd = (float)hi + (float)(__bf16)(dd - (float)hi);
+                    }
+                    a4[j] = dd;
+                }
+            }
+            __syncthreads();
+            const unsigned m = okm[d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                As[a_px][a_c4 + j] = (m >> 8) & 1u ? a4[j] : 0.f;
+                Bs[pl][g + 16 * j] = (m >> j) & 1u ? rb[d][j] : 0.f;
+            }
+            __syncthreads();
+            load(d, pc + D * TW_RC);
+#pragma unroll
+            for (int ks = 0; ks < TW_RC / 4; ++ks) {
+                const float a = As[4 * ks + q][16 * mt + r];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[4 * ks + q][16 * (2 * nh + n) + r], acc[n], 0, 0, 0);
+            }
+        }
+    }
+    float *pb = partial + (size_t)slice * c.Cout * c.Kdim;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int k = kc0 + 16 * (2 * nh + n) + r;
+        if (k >= c.Kdim) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + 16 * mt + 4 * q + i;
             if (co < c.Cout) pb[(size_t)co * c.Kdim + k] = acc[n][i];
         }
     }
@@ -2375,8 +2532,8 @@ int pn_stem_forward_planes(pn_ctx *ctx, const float *x_dev, const float *w_dev, 
     return PN_OK;
 }
 
-int pn_stem_wgrad_planes(pn_ctx *ctx, const float *x_dev, const void *dy_planes, int cs, int split, int f32, float *dw_dev, int N, int Cin, int H, int W, int Cout,
-                         int ks, int stride, int pad, hipStream_t s) {
+int pn_stem_wgrad_planes(pn_ctx *ctx, const float *x_dev, const void *dy_planes, int cs, int split, int f32, const PnStemBn *bn, float *dw_dev, int N, int Cin, int H,
+                         int W, int Cout, int ks, int stride, int pad, int depth, hipStream_t s) {
     T_CTX_CHECK("pn_stem_wgrad_planes")
     TConv c;
     if (int rc = t_stem_conv(ctx, &c, x_dev, (void *)dy_planes, cs, split, N, Cin, H, W, Cout, ks, stride, pad)) return rc;
@@ -2394,9 +2551,28 @@ int pn_stem_wgrad_planes(pn_ctx *ctx, const float *x_dev, const void *dy_planes,
     const size_t wn = (size_t)Cout * c.Kdim;
     void *ws = nullptr;
     if (int rc = t_ws(ctx, wn * slices * sizeof(float) + 16, &ws)) return rc;
-    dim3 grid((unsigned)((c.Kdim + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)slices), block(256);
-    if (f32) hipLaunchKernelGGL((tconv_wgrad_kernel<7, 2>), grid, block, 0, s, c, (float *)ws, (int)pps);
-    else hipLaunchKernelGGL((tconv_wgrad_kernel<7, 1>), grid, block, 0, s, c, (float *)ws, (int)pps);
+    dim3 grid((unsigned)((c.Kdim + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)slices), block(512);
+    TStemBn b = TStemBn();
+    if (bn) {
+        if (!bn->x || !bn->mean || !bn->invstd || !bn->k1 || !bn->k2 || !bn->k3 || !bn->scale || !bn->shift || (bn->x_cs & 7) || (bn->x_split & 7))
+            return pn_set_error(ctx, PN_ERR_INVALID, "pn_stem_wgrad_planes: incomplete BatchNorm description");
+        b.x = bn->x; b.x_cs = bn->x_cs; b.x_split = bn->x_split; b.mean = bn->mean; b.invstd = bn->invstd; b.k1 = bn->k1; b.k2 = bn->k2; b.k3 = bn->k3;
+        b.scale = bn->scale; b.shift = bn->shift; b.act = bn->act;
+    }
+    float *wsf = (float *)ws;
+    const int pp = (int)pps;
+#define TSTEM_LAUNCH(F, B, D) hipLaunchKernelGGL((tstem_wgrad_kernel<7, F, B, D>), grid, block, 0, s, c, b, wsf, pp)
+    if (depth <= 1) {        // (one chunk in flight: tconv_wgrad_kernel's schedule, for A/B runs)
+        if (f32) { if (bn) TSTEM_LAUNCH(1, 1, 1); else TSTEM_LAUNCH(1, 0, 1); }
+        else { if (bn) TSTEM_LAUNCH(0, 1, 1); else TSTEM_LAUNCH(0, 0, 1); }
+    } else if (depth < 4) {
+        if (f32) { if (bn) TSTEM_LAUNCH(1, 1, 2); else TSTEM_LAUNCH(1, 0, 2); }
+        else { if (bn) TSTEM_LAUNCH(0, 1, 2); else TSTEM_LAUNCH(0, 0, 2); }
+    } else {
+        if (f32) { if (bn) TSTEM_LAUNCH(1, 1, 4); else TSTEM_LAUNCH(1, 0, 4); }
+        else { if (bn) TSTEM_LAUNCH(0, 1, 4); else TSTEM_LAUNCH(0, 0, 4); }
+    }
+#undef TSTEM_LAUNCH
     t_wgrad_reduce(s, (const float *)ws, dw_dev, wn, (int)slices);
     PN_HIP_CHECK(ctx, hipGetLastError());
     return PN_OK;

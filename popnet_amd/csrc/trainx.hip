@@ -409,7 +409,7 @@ void op_bn_bwd(pn_trainer *t, std::vector<BnBwdUse> uses) {
         for (int i = 0; i < n; ++i) {
             const BnBwdUse &u = uses[i];
             const TxBn &b = t->bns[u.bn];
-            const TxTensor X = t->T[u.x], DY = t->T[u.dy], Y = t->T[u.y], DX = t->T[u.dx];
+            const TxTensor X = t->T[u.x], DY = t->T[u.dy], Y = t->T[u.y], DX = u.dx >= 0 ? t->T[u.dx] : TxTensor();
             // the activation's sign: from the stored output when a residual went into it, else recomputed from x (one tensor less to read)
             const char *ysrc = (u.act && u.has_res) ? Y.p : nullptr;
             tx::RedArgs &ri = r.a[i];
@@ -429,6 +429,10 @@ void op_bn_bwd(pn_trainer *t, std::vector<BnBwdUse> uses) {
         if (t->f32) hipLaunchKernelGGL((tx::reduce_kernel<1, float>), dim3(max_nblk, n), dim3(256), 0, s, r);
         else hipLaunchKernelGGL((tx::reduce_kernel<1, bf>), dim3(max_nblk, n), dim3(256), 0, s, r);
         hipLaunchKernelGGL(tx::bn_bwd_finish_kernel, dim3((max_c + 3) / 4, n), dim3(256), 0, s, f);
+        if (uses[0].dx < 0) {                     // sums and k1 / k2 / k3 only: the consumer applies them itself (the stem's weight gradient)
+            PN_HIP_CHECK(t->ctx, hipGetLastError());
+            return (int)PN_OK;
+        }
         if (t->f32) hipLaunchKernelGGL(tx::bn_bwd_apply_kernel<float>, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(tx::bn_bwd_apply_kernel<bf>, dim3(grid_for(max_items, t->ctx->num_cus), n), dim3(256), 0, s, a);
         PN_HIP_CHECK(t->ctx, hipGetLastError());
@@ -819,20 +823,33 @@ int build(pn_trainer *t) {
     TX(TT(H4, W4, 64, &dP1));
     TX(block_bwd(b20, dA6, H4, W4, 64, 128, &dP1, s56));
     // (own scratch per block: a weight gradient still running on the side stream reads dC2 / dC1 of its block)
-    int s112[6], s112b[6], dA4, dA2, dA0, dC0;
+    // the stem's BatchNorm backward is applied inside its weight-gradient kernel (train.hip::tstem_wgrad_kernel): dC0 never exists
+    const bool stem_handover = getenv("POPNET_TRAINX_STEM_HANDOVER") != nullptr;      // A/B: the NCHW f32 hand-over of the round's first builds (bit-identical)
+    const char *esb = getenv("POPNET_TRAINX_STEM_BN");
+    const bool stem_bn_separate = stem_handover || (esb && !strcmp(esb, "separate"));  // A/B: bn_bwd_apply_kernel writes dC0, the weight gradient reads it (bit-identical)
+    const char *esd = getenv("POPNET_TRAINX_STEM_DEPTH");
+    const int stem_depth = esd ? atoi(esd) : 1;                                         // A/B: chunks of 32 pixels in flight per block (1, 2, 4; bit-identical): 105.8 / 111.2 / 116.1 us -- not latency-bound
+    int s112[6], s112b[6], dA4, dA2, dA0, dC0 = -1;
     for (int i = 0; i < 4; ++i) { TX(TT(H2, W2, 64, &s112[i])); TX(TT(H2, W2, 64, &s112b[i])); }
     s112[4] = s112[5] = s112b[4] = s112b[5] = -1;
-    TX(TT(H2, W2, 64, &dA4)); TX(TT(H2, W2, 64, &dA2)); TX(TT(H2, W2, 64, &dC0));
+    TX(TT(H2, W2, 64, &dA4)); TX(TT(H2, W2, 64, &dA2));
+    if (stem_bn_separate) TX(TT(H2, W2, 64, &dC0));
     op_pool_bwd(t, dP1, dA4);
     TX(block_bwd(b11, dA4, H2, W2, 64, 64, &dA2, s112));
     dA0 = dA4;                                   // free again: layer1.1's output gradient has been consumed (by launches of the step's own stream)
     TX(block_bwd(b10, dA2, H2, W2, 64, 64, &dA0, s112b));
-    op_bn_bwd(t, bn_stem, C0, dA0, A0, dC0, -1, 1, false);
+    op_bn_bwd(t, bn_stem, C0, dA0, A0, stem_bn_separate ? dC0 : -1, -1, 1, false);
     {
-        const TxTensor d0 = t->T[dC0];
-        const bool handover = getenv("POPNET_TRAINX_STEM_HANDOVER") != nullptr;
+        const TxTensor d0 = dC0 >= 0 ? t->T[dC0] : TxTensor(), a0 = t->T[dA0], c0 = t->T[C0];
         t->ops.push_back([=](hipStream_t s) {
-            if (!handover) return pn_stem_wgrad_planes(t->ctx, t->img, d0.p, d0.cs(), d0.split(), t->f32, dw_stem, B, 1, H, W, 64, 7, 2, 3, s);
+            if (!stem_bn_separate) {
+                const TxBn &b = t->bns[bn_stem];
+                PnStemBn sb;
+                sb.x = c0.p; sb.x_cs = c0.cs(); sb.x_split = c0.split();
+                sb.mean = b.mean; sb.invstd = b.invstd; sb.k1 = b.k1; sb.k2 = b.k2; sb.k3 = b.k3; sb.scale = b.scale; sb.shift = b.shift; sb.act = 1;
+                return pn_stem_wgrad_planes(t->ctx, t->img, a0.p, a0.cs(), a0.split(), t->f32, &sb, dw_stem, B, 1, H, W, 64, 7, 2, 3, stem_depth, s);
+            }
+            if (!stem_handover) return pn_stem_wgrad_planes(t->ctx, t->img, d0.p, d0.cs(), d0.split(), t->f32, nullptr, dw_stem, B, 1, H, W, 64, 7, 2, 3, stem_depth, s);
             const int HW = H2 * W2;
             if (t->f32) hipLaunchKernelGGL(tx::planes_to_nchw_kernel<float>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)d0.p, d0.cs(), 0, t->nchw_b, 64, HW, (const int *)nullptr);
             else hipLaunchKernelGGL(tx::planes_to_nchw_kernel<bf>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const bf *)d0.p, d0.cs(), d0.plane, t->nchw_b, 64, HW, (const int *)nullptr);
