@@ -71,7 +71,7 @@ template <> struct Lay<float> {
 // MODE 1: s0 = sum g, s1 = sum g * xhat                  (BatchNorm backward: g = dy * act'(y), xhat = (x - mean) * invstd)
 // MODE 2: s0 = sum x                                     (bias gradient)
 // Block = 256 threads = (C / 8 channel groups) x (256 / (C / 8) pixel lanes); block b owns pixels [b * ppb, (b + 1) * ppb).
-// partial[(block * C + c) * 2 + {0, 1}] (double).
+// partial[(c * nblk + block) * 2 + {0, 1}] (double).
 // Independent tensors of a level (the three branches of a stage) share a launch: blockIdx.y = problem.
 template <typename A> struct Multi { A a[3]; };
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(Multi<RedArgs> mm) {
         const int which = o / a.C, c = o % a.C;
         double s = 0.0;
         for (int l = 0; l < PL; ++l) s += (double)sh[which][l * G + (c >> 3)][c & 7];
-        a.partial[((size_t)blockIdx.x * a.C + c) * 2 + which] = s;
+        a.partial[((size_t)c * a.nblk + blockIdx.x) * 2 + which] = s;       // [channel][block][2]: a finish wave reads its channel's partials as consecutive KBs
     }
 }
 
@@ -158,7 +158,9 @@ struct BnFinArgs {
 __device__ __forceinline__ void wave_sum2(const double *__restrict__ partial, int nblk, int C, int c, double &s0, double &s1) {
     const int lane = threadIdx.x & 63;
     s0 = 0.0; s1 = 0.0;
-    for (int b = lane; b < nblk; b += 64) { s0 += partial[((size_t)b * C + c) * 2]; s1 += partial[((size_t)b * C + c) * 2 + 1]; }
+    (void)C;
+    const double *pc = partial + (size_t)c * nblk * 2;             // (round 6, late: was [block][channel][2] -- every lane of every load in a line of its own)
+    for (int b = lane; b < nblk; b += 64) { const double2 v = *reinterpret_cast<const double2 *>(pc + 2 * b); s0 += v.x; s1 += v.y; }
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
 }
 __global__ __launch_bounds__(256) void bn_finish_kernel(Multi<BnFinArgs> mm) {
