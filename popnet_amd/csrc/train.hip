@@ -1640,8 +1640,8 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
 //     256 CUs leave 136 CUs with two blocks: with half the staging work per wave a slice takes half as long.  Wave w accumulates cout tile w & 3 x k-column
 //     tiles 2 (w >> 2), 2 (w >> 2) + 1 -- every accumulator sees the MFMAs of tconv_wgrad_kernel in the same order;
 //   * D chunks in flight (template parameter; every load of a slot issued unconditionally and the prologue in slot order, or the compiler closes each
-//     iteration with s_waitcnt vmcnt(0)): measured 105.8 / 111.2 / 116.1 us for D = 1 / 2 / 4 on one box -- the launch is bound by instruction issue
-//     (~270 instructions per wave and 32-pixel chunk for 16 MFMAs), not by memory latency; D = 1 is the default.
+//     iteration with s_waitcnt vmcnt(0)): D = 2 is the default -- 83-91 us in the step's traces against 102-163 (D = 1, unsteady) and 105 (D = 4); the
+//     launch is bound by instruction issue (~270 instructions per wave and 32-pixel chunk for 16 MFMAs; SQ_INSTS_VALU / SQ_INSTS_MFMA 12.6), not by latency.
 // ---------------------------------------------------------------------------------------------------------------------
 struct TStemBn {
     const void *x; int x_cs, x_split;            // the convolution output (planes, as dY)
@@ -1650,20 +1650,24 @@ struct TStemBn {
 };
 template <int KS, int F32, int BN, int D>
 __global__ __launch_bounds__(512, 1) void tstem_wgrad_kernel(TConv c, TStemBn bn, float *__restrict__ partial, int pix_per_slice) {
-    __shared__ float As[TW_RC][TW_P];      // dY  [pixel][cout]
-    __shared__ float Bs[TW_RC][TW_P];      // X   [pixel][k column]
+    // pitch 80 floats: the four pixel rows q of an MFMA operand read sit 16 banks apart (80 % 32 = 16: lanes (q, r) of a half-wave on 32 different banks; the
+    // 81 of tconv_wgrad_kernel gives every such read a two-way conflict, 47 % of this kernel's LDS cycles by SQ_LDS_BANK_CONFLICT), and a thread's four
+    // staged values are one aligned 16-byte store
+    constexpr int TSP = 80;
+    __shared__ __attribute__((aligned(16))) float As[TW_RC][TSP];      // dY  [pixel][cout]
+    __shared__ __attribute__((aligned(16))) float Bs[TW_RC][TSP];      // X   [pixel][k column]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
     const int mt = wave & 3, nh = wave >> 2;            // this wave's cout tile and pair of k-column tiles
     T_DECODE_XYZ(bx_, by_, slice);
     const int kc0 = bx_ * 64, co0 = by_ * 64;
     const int HoWo = c.Ho * c.Wo;
-    const int pl = t & 31, g = t >> 5;                  // X staging: pixel, k columns g + 16 j
+    const int pl = t & 31, g = t >> 5;                  // X staging: pixel, k columns 4 g + j
     // (the vector instructions bound this kernel: everything that does not change from chunk to chunk is decided here -- a k column's offset inside the
     // image and its (ky, kx); an invalid column gets ky = -2^20, which fails the halo test)
     int koff[4], kky[4], kkx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int k = kc0 + g + 16 * j;
+        const int k = kc0 + 4 * g + j;
         if (k < c.Kdim) {
             const int ci = k / (KS * KS), rr = k - ci * (KS * KS);
             kky[j] = rr / KS;
@@ -1774,10 +1778,10 @@ __global__ __launch_bounds__(512, 1) void tstem_wgrad_kernel(TConv c, TStemBn bn
             }
             __syncthreads();
             const unsigned m = okm[d];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                As[a_px][a_c4 + j] = (m >> 8) & 1u ? a4[j] : 0.f;
-                Bs[pl][g + 16 * j] = (m >> j) & 1u ? rb[d][j] : 0.f;
+            {
+                const bool aok = (m >> 8) & 1u;
+                *reinterpret_cast<t_f32x4 *>(&As[a_px][a_c4]) = t_f32x4{aok ? a4[0] : 0.f, aok ? a4[1] : 0.f, aok ? a4[2] : 0.f, aok ? a4[3] : 0.f};
+                *reinterpret_cast<t_f32x4 *>(&Bs[pl][4 * g]) = t_f32x4{m & 1u ? rb[d][0] : 0.f, m & 2u ? rb[d][1] : 0.f, m & 4u ? rb[d][2] : 0.f, m & 8u ? rb[d][3] : 0.f};
             }
             __syncthreads();
             load(d, pc + D * TW_RC);

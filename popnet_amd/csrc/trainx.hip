@@ -828,7 +828,7 @@ int build(pn_trainer *t) {
     const char *esb = getenv("POPNET_TRAINX_STEM_BN");
     const bool stem_bn_separate = stem_handover || (esb && !strcmp(esb, "separate"));  // A/B: bn_bwd_apply_kernel writes dC0, the weight gradient reads it (bit-identical)
     const char *esd = getenv("POPNET_TRAINX_STEM_DEPTH");
-    const int stem_depth = esd ? atoi(esd) : 1;                                         // A/B: chunks of 32 pixels in flight per block (1, 2, 4; bit-identical): 105.8 / 111.2 / 116.1 us -- not latency-bound
+    const int stem_depth = esd ? atoi(esd) : 2;                                         // A/B: chunks of 32 pixels in flight per block (1, 2, 4; bit-identical): 102-163 / 83-91 / 105 us over six traces
     int s112[6], s112b[6], dA4, dA2, dA0, dC0 = -1;
     for (int i = 0; i < 4; ++i) { TX(TT(H2, W2, 64, &s112[i])); TX(TT(H2, W2, 64, &s112b[i])); }
     s112[4] = s112[5] = s112b[4] = s112b[5] = -1;
