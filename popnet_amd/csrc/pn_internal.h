@@ -197,8 +197,9 @@ int pn_launch_pool(pn_ctx *ctx, int prec, int mode, const void *in, void *out, i
 // NCHW f32 -> ReLU -> NHWC T (the multi-channel stem's hand-over, conv_misc.hip)
 // train.hip: model0.conv1 of the planes training engine (trainx.hip) -- output / output gradient as a planes tensor [pixel][cs] (f32 != 0: one
 // f32 plane; else two bf16 planes [hi | lo] `split` elements apart)
+// gather != 0: tconv_fwd_kernel's element-by-element operand gather (A/B; bit-identical) instead of the input patch in LDS
 int pn_stem_forward_planes(pn_ctx *ctx, const float *x_dev, const float *w_dev, void *y_planes, int cs, int split, int f32, int N, int Cin, int H, int W, int Cout,
-                           int ks, int stride, int pad, hipStream_t s);
+                           int ks, int stride, int pad, int gather, hipStream_t s);
 // bn != nullptr: `dy_planes` is the gradient w.r.t. the BatchNorm + activation OUTPUT and the kernel applies the BatchNorm backward itself (k1, k2, k3: what
 // trainx_kernels.h::bn_bwd_finish_kernel leaves); depth = chunks of 32 pixels in flight per block (1 or 4)
 struct PnStemBn {

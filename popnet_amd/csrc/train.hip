@@ -1628,6 +1628,105 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(TConv c, float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The planes training engine's stem forward (round 6, late): model0.conv1 = 7x7 / 2, ONE input channel, 64 couts, on the same fp32 MFMA with the same
+// k order as tconv_fwd_kernel<7> (k = tap, four taps per v_mfma_f32_16x16x4_f32, k-steps in order: bit-identical), without that kernel's staging: it
+// gathers the [k][pixel] operand element by element for every 16-tap chunk and restages the weights per chunk (13.7 vector instructions per MFMA by
+// SQ_INSTS_VALU / SQ_INSTS_MFMA, 82 us at the head of the step).  With one input channel the operand of tap (ky, kx) IS the input image shifted by
+// (ky, kx): a block stages the 21 x 37 input patch of an 8 x 16 output tile once and every lane reads its B value at  base(pixel) + offset(tap)  --
+// thirteen per-lane tap offsets for the whole kernel; the 64 x 49 weight matrix is 52 A-fragment registers per lane, loaded once per block, and a
+// block walks tiles (two blocks per CU).  Alone 73 -> 41 us; beside the weight packs at the head of the step 82 -> 56 us.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int F32>
+__global__ __launch_bounds__(256) void tstem_fwd_kernel(TConv c, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int TR = 8, TC = 16, IR = (TR - 1) * 2 + 7, IC = (TC - 1) * 2 + 7;      // output tile, input patch (21 x 37)
+    __shared__ float img[IR * IC];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane >> 4, r = lane & 15;
+    float a[4][13];
+    int tapoff[13];
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+        const int k = 4 * s + q;
+        const bool ok = k < 49;
+        tapoff[s] = ok ? (k / 7) * IC + (k % 7) : 0;          // (a padding tap multiplies a zero weight with the patch's own first element)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m][s] = ok ? c.w[(16 * (r >> 2) + 4 * m + (r & 3)) * 49 + k] : 0.f;      // row r of tile m = cout 16 (r >> 2) + 4 m + (r & 3): a lane's sixteen accumulators are couts 16 q ..+15
+    }
+    const int base0 = (2 * (2 * wave)) * IC + 2 * r, base1 = base0 + 2 * IC;      // this wave's two output rows of the tile, pixel column r
+    // the patch of tile n + 1 is fetched (four values per thread, all four loads in flight) while tile n runs: a block's round trip to the input is never exposed
+    // (the first form fetched and stored them one after the other at the head of the tile: four dependent round trips, 60 us for 17 us of MFMA work)
+    constexpr int NS = (IR * IC + 255) / 256;
+    float sv[NS];
+    unsigned sok = 0;
+    auto fetch = [&](int tile) {
+        const int b = tile / (tiles_x * tiles_y), rem = tile - b * (tiles_x * tiles_y), ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int iy0 = ty * TR * 2 - 3, ix0 = tx * TC * 2 - 3;
+        const float *xb = c.x + (size_t)b * c.H * c.W;
+        sok = 0;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = t + 256 * u, rr = i / IC, cc = i - rr * IC, iy = iy0 + rr, ix = ix0 + cc;
+            const bool ok = i < IR * IC && (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
+            sv[u] = xb[ok ? iy * c.W + ix : 0];
+            sok |= (unsigned)ok << u;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y), rem = tile - b * (tiles_x * tiles_y), ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int oy0 = ty * TR, ox0 = tx * TC;
+        __syncthreads();                                       // the previous tile's reads are done
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            if (t + 256 * u < IR * IC) img[t + 256 * u] = (sok >> u) & 1u ? sv[u] : 0.f;
+        __syncthreads();
+        fetch(min(tile + (int)gridDim.x, ntiles - 1));         // (unconditional: a straight-line loop body keeps the compiler's wait counts exact)
+        t_f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 13; ++s) {
+            const float b0 = img[base0 + tapoff[s]], b1 = img[base1 + tapoff[s]];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b1, acc[m][1], 0, 0, 0);
+            }
+        }
+        // lane holds couts 16 q + 4 m + i of pixel (row 2 wave + n, column r): 32 contiguous bytes per plane, the four q lanes of a pixel one 128-byte line
+        // (with the natural row order -- couts 16 m + 4 q + i -- a line was written by four 8-byte stores per lane quartet: 76 us, as slow as the gather kernel)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int oy = oy0 + 2 * wave + n, ox = ox0 + r;
+            if (oy >= c.Ho || ox >= c.Wo) continue;
+            const size_t p = ((size_t)b * c.Ho + oy) * c.Wo + ox;
+            float v[16];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * m + i] = acc[m][n][i] + 0.f;          // (tconv_fwd_kernel adds its zero bias: -0 becomes +0 there as well)
+            if (F32) {
+                float *o = (float *)c.pl + p * c.pl_cs + 16 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<t_f32x4 *>(o + 4 * j) = t_f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+            } else {
+                t_bf8 h[2], l[2];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const __bf16 hi = (__bf16)v[j];
+                    h[j >> 3][j & 7] = hi;
+                    l[j >> 3][j & 7] = (__bf16)(v[j] - (float)hi);
+                }
+                __bf16 *o = (__bf16 *)c.pl + p * c.pl_cs + 16 * q;
+                *reinterpret_cast<t_bf8 *>(o) = h[0];
+                *reinterpret_cast<t_bf8 *>(o + 8) = h[1];
+                *reinterpret_cast<t_bf8 *>(o + c.pl_split) = l[0];
+                *reinterpret_cast<t_bf8 *>(o + c.pl_split + 8) = l[1];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The planes training engine's stem weight gradient (round 6): tconv_wgrad_kernel above -- the same block roles for the MFMAs, the same
 // slices, the same order of every sum: bit-identical partials -- with
 //   * dY read from a planes tensor ([pixel][cs], two bf16 planes hi | lo or one f32 plane): thread = (pixel t >> 3, couts 8 (t & 7) ..+7),
@@ -2523,12 +2622,24 @@ static int t_stem_conv(pn_ctx *ctx, TConv *c, const float *x_dev, void *planes, 
 }
 
 int pn_stem_forward_planes(pn_ctx *ctx, const float *x_dev, const float *w_dev, void *y_planes, int cs, int split, int f32, int N, int Cin, int H, int W, int Cout,
-                           int ks, int stride, int pad, hipStream_t s) {
+                           int ks, int stride, int pad, int gather, hipStream_t s) {
     T_CTX_CHECK("pn_stem_forward_planes")
     TConv c;
     if (int rc = t_stem_conv(ctx, &c, x_dev, y_planes, cs, split, N, Cin, H, W, Cout, ks, stride, pad)) return rc;
     if (!w_dev) return pn_set_error(ctx, PN_ERR_INVALID, "pn_stem_forward_planes: no weights");
     c.w = w_dev;
+    if (!gather && Cin == 1 && Cout == 64 && stride == 2 && pad == 3) {         // the input patch in LDS (tstem_fwd_kernel)
+        const int tiles_x = (c.Wo + 15) / 16, tiles_y = (c.Ho + 7) / 8;
+        const long ntiles = (long)N * tiles_x * tiles_y;
+        // blocks per CU, one-stream traces of the step: 1: 49.1, 2: 41.5, 3: 42.8, 4: 45.0, 6: 48.3, 12: 62.2 us (three are resident at 148 registers; every block
+        // loads the 52 weight registers once) -- POPNET_STEM_FWD_BLOCKS overrides
+        const char *eb = getenv("POPNET_STEM_FWD_BLOCKS");
+        const unsigned blocks = (unsigned)std::min<long>(ntiles, (long)ctx->num_cus * (eb ? std::max(1, atoi(eb)) : 2));
+        if (f32) hipLaunchKernelGGL(tstem_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, c, tiles_x, tiles_y, (int)ntiles);
+        else hipLaunchKernelGGL(tstem_fwd_kernel<0>, dim3(blocks), dim3(256), 0, s, c, tiles_x, tiles_y, (int)ntiles);
+        PN_HIP_CHECK(ctx, hipGetLastError());
+        return PN_OK;
+    }
     dim3 grid((unsigned)((c.P + 127) / 128), (unsigned)((Cout + 63) / 64)), block(256);
     if (f32) hipLaunchKernelGGL((tconv_fwd_kernel<7, 2>), grid, block, 0, s, c);
     else hipLaunchKernelGGL((tconv_fwd_kernel<7, 1>), grid, block, 0, s, c);

@@ -657,8 +657,10 @@ int build(pn_trainer *t) {
     {
         const TxTensor c0 = t->T[C0];
         const bool handover = getenv("POPNET_TRAINX_STEM_HANDOVER") != nullptr;      // the NCHW f32 hand-over of the round's first builds (bit-identical; A/B)
+        const char *esf = getenv("POPNET_TRAINX_STEM_FWD");
+        const int stem_gather = esf && !strcmp(esf, "gather");                        // A/B: tconv_fwd_kernel<7, PL> instead of tstem_fwd_kernel (bit-identical)
         t->ops.push_back([=](hipStream_t s) {
-            if (!handover) return pn_stem_forward_planes(t->ctx, t->img, w_stem, c0.p, c0.cs(), c0.split(), t->f32, B, 1, H, W, 64, 7, 2, 3, s);
+            if (!handover) return pn_stem_forward_planes(t->ctx, t->img, w_stem, c0.p, c0.cs(), c0.split(), t->f32, B, 1, H, W, 64, 7, 2, 3, stem_gather, s);
             if (int r = pn_conv2d_forward(t->ctx, t->img, w_stem, nullptr, t->nchw_a, B, 1, H, W, 64, 7, 2, 3, 0, (void *)s)) return r;
             const int HW = H2 * W2;
             if (t->f32) hipLaunchKernelGGL(tx::nchw_to_planes_kernel<float>, dim3((HW + 63) / 64, 1, B), dim3(256), 0, s, (const float *)t->nchw_a, (float *)c0.p, 64, HW, c0.cs(), 0);

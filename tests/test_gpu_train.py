@@ -528,7 +528,7 @@ def test_planes_engine_weight_gradient_kernel_and_stream_split_are_exact_restate
     assert float(two.g["model0.conv1.weight"].abs().max()) > 0
     for k in two.stats:
         assert torch.equal(hand.stats[k], two.stats[k]), k
-    for env in ({"POPNET_TRAINX_STEM_BN": "separate"}, {"POPNET_TRAINX_STEM_DEPTH": "1"}, {"POPNET_TRAINX_STEM_BN": "separate", "POPNET_TRAINX_STEM_DEPTH": "4"}):
+    for env in ({"POPNET_TRAINX_STEM_FWD": "gather"}, {"POPNET_TRAINX_STEM_BN": "separate"}, {"POPNET_TRAINX_STEM_DEPTH": "1"}, {"POPNET_TRAINX_STEM_BN": "separate", "POPNET_TRAINX_STEM_DEPTH": "4"}):
         alt, ta = run(**env)
         assert torch.equal(ta, t2) and torch.equal(alt.flat_g, two.flat_g), env
     gat, tg = run(POPNET_TRAINX_PACK="gather")
