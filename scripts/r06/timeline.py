@@ -1,5 +1,5 @@
 """One training step as a timeline: every launch between two sgd_nesterov launches of a rocprofv3 --kernel-trace csv, with its start offset, duration and queue, plus the
-time during which only one / both queues hold a running kernel.  usage: timeline.py <dir> [step index]"""
+time during which only one / both queues hold a running kernel.  usage: timeline.py <dir> [step index] [marker kernel prefix = sgd_nesterov] [steps to show = 1]"""
 import csv
 import glob
 import os
@@ -10,8 +10,10 @@ which = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 f = glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?")) for r in csv.DictReader(open(f))]
 rows.sort()
-marks = [i for i, r in enumerate(rows) if r[2].startswith("sgd_nesterov")]
-a, b = marks[which] + 1, marks[which + 1] + 1
+marker = sys.argv[3] if len(sys.argv) > 3 else "sgd_nesterov"
+span = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+marks = [i for i, r in enumerate(rows) if r[2].startswith(marker)]
+a, b = marks[which] + 1, marks[which + span] + 1
 step = rows[a:b]
 t0 = rows[marks[which]][1]
 qs = sorted(set(r[3] for r in step))

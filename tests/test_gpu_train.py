@@ -543,6 +543,34 @@ def test_planes_engine_weight_gradient_kernel_and_stream_split_are_exact_restate
     assert torch.equal(two.g["model0.conv1.weight"], leg.g["model0.conv1.weight"])        # the stem keeps train.hip's kernel in both
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp32"])
+def test_planes_engine_restatements_where_the_stage_levels_run_conv4_and_the_stem_tiles_are_ragged(gpu, golden, monkeypatch, prec):
+    """The exact-restatement switches once more at a batch shape the small cases do not reach: 16 frames of 328 x 488 -- 41 x 61 stage maps (>= 448 conv4 blocks per level in
+    bf16x3: the conv4 fragment order of the weight packs), 164 x 244 stem maps (8 x 16 stem tiles cut on both edges; 640 332 stem pixels = 625.3 slices of 1 024)."""
+    from popnet_amd.train import TrainEngine
+    sd = init_like_state_dict(golden.keys["rtpose_light3d"], seed=11)
+    batch = [torch.from_numpy(a).to(gpu) for a in train_case_inputs(seed=912, B=16, H=328, W=488)]
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = TrainEngine(sd, device=gpu, precision=prec)
+        t = e.forward_backward(*batch).clone()
+        g = e.flat_g.clone()
+        torch.cuda.synchronize()
+        for k in env:
+            monkeypatch.delenv(k)
+        del e
+        torch.cuda.empty_cache()
+        return t, g
+    t0, g0 = run()
+    assert bool(torch.isfinite(g0).all()) and float(g0.abs().max()) > 0
+    for env in ({"POPNET_TRAINX_PACK": "gather"}, {"POPNET_TRAINX_STEM_FWD": "gather", "POPNET_TRAINX_STEM_BN": "separate", "POPNET_TRAINX_STEM_DEPTH": "1"},
+                {"POPNET_TRAINX_STEM_HANDOVER": "1", "POPNET_TRAINX_STREAMS": "1"}):
+        t1, g1 = run(**env)
+        assert torch.equal(t1, t0) and torch.equal(g1, g0), env
+
+
 @pytest.mark.parametrize("B", [2, 5])
 def test_training_step_at_network_input_size(gpu, golden, B):
     """224x224 (the training configuration's input) from the initial state: loss terms to 1e-5; gradients in torch fp32's own
